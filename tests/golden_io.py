@@ -1,0 +1,80 @@
+"""Helpers shared by the parity tests: load the golden fixtures and rebuild the exact seeded inputs they were
+generated from (`tests/golden/make_golden.py`), checking the stored input checksums so generator drift is loud."""
+from __future__ import annotations
+
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from iisan_amd import synth, weights
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRAD_STRIDE = 97
+GRAD_FULL_MAX = 5000
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def load(name: str):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sample_like_golden(t: torch.Tensor) -> np.ndarray:
+    g = t.detach().cpu().reshape(-1)
+    return (g if g.numel() <= GRAD_FULL_MAX else g[::GRAD_STRIDE]).numpy()
+
+
+def encoders_full_inputs():
+    z = load("encoders_full.npz")
+    vw = weights.make_vit_weights(weights.VIT_BASE, seed=int(z["vit_seed"]))
+    bw = weights.make_bert_weights(weights.BERT_BASE, seed=int(z["bert_seed"]))
+    assert sha(vw["L11.fc2_w"]) == str(z["w_sha"][0]) and sha(bw["word_emb"]) == str(z["w_sha"][1]), \
+        "seeded weight generator drifted from the golden fixture"
+    b = synth.scientific_batch(bs=1, seed=int(z["batch_seed"]), seq_len=3, lengths=[3])
+    assert sha(b.images) == str(z["images_sha"]), "seeded image generator drifted from the golden fixture"
+    assert np.array_equal(b.text.numpy(), z["text"])
+    return z, vw, bw, b
+
+
+def sidenet_full_inputs(variant: str = "default"):
+    z = load("sidenet_full.npz")
+    b = synth.scientific_batch(bs=3, seed=77, lengths=[4, 11, 7], dup_items=True, res=16, item_num=50)
+    assert np.array_equal(b.ids.numpy(), z["ids"]) and np.array_equal(b.pop_prob.numpy(), z["pop"])
+    taps_cv = synth.cached_taps(b.ids, 12, 768, seed=5)
+    taps_tx = synth.cached_taps(b.ids, 12, 768, seed=6)
+    assert sha(taps_cv) == str(z["taps_sha"][0]) and sha(taps_tx) == str(z["taps_sha"][1])
+    P = weights.make_trainable_params(seed=99, cached=True, n_side=6 if variant == "rmfirst" else 7)
+    kw = dict(default={}, gelu=dict(activation="GELU"), rmfirst=dict(remove_first=True))[variant]
+    return z, b, taps_cv, taps_tx, P, kw
+
+
+E2E_VIT = weights.VitConfig(hidden=768, layers=2, heads=12, mlp=512, image=32, patch=16)
+E2E_BERT = weights.BertConfig(hidden=768, layers=2, heads=12, mlp=512, vocab=512, max_pos=64)
+
+
+def e2e_small_inputs():
+    z = load("e2e_small.npz")
+    vw, bw = weights.make_vit_weights(E2E_VIT, seed=11), weights.make_bert_weights(E2E_BERT, seed=12)
+    b = synth.scientific_batch(bs=3, seed=31, lengths=[3, 11, 6], dup_items=True, res=32, words=8, vocab=512,
+                               item_num=40)
+    assert sha(b.images) == str(z["images_sha"]) and np.array_equal(b.text.numpy(), z["text"])
+    assert np.array_equal(b.ids.numpy(), z["ids"])
+    P = weights.make_trainable_params(seed=101, n_side=3)
+    return z, vw, bw, b, P
+
+
+def eval_inputs():
+    z = load("eval.npz")
+    lens = z["seq_len"]
+    flat = z["seq_flat"]
+    seqs, o = [], 0
+    for l in lens:
+        seqs.append([int(x) for x in flat[o:o + int(l)]])
+        o += int(l)
+    P = weights.make_trainable_params(seed=99, cached=True)
+    tables = [torch.from_numpy(z[k]) for k in ("table_cv", "table_text", "table_mm")]
+    return z, seqs, tables, P
