@@ -1,0 +1,104 @@
+"""ctypes binding of libiisan_hip.so (the C ABI declared in include/iisan_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent, importing the ops fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiisan_hip.so")
+
+IISAN_F16, IISAN_BF16 = 0, 1
+MAX_LAYERS, MAX_SIDE = 48, 16
+
+vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                  "ln1_w", "ln1_b", "ln2_w", "ln2_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("mlp", i32),
+                ("image", i32), ("patch", i32), ("channels", i32), ("dtype16", i32), ("eps", f32),
+                ("patch_w", vp), ("patch_b", vp), ("cls_token", vp), ("pos_emb", vp),
+                ("layer", LayerWeights * MAX_LAYERS)]
+
+
+class BertWeights(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("mlp", i32),
+                ("vocab", i32), ("max_pos", i32), ("dtype16", i32), ("eps", f32),
+                ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
+                ("layer", LayerWeights * MAX_LAYERS)]
+
+
+class SideCfg(C.Structure):
+    _fields_ = [("n_side", i32), ("dim_cv", i32), ("dim_text", i32), ("down", i32), ("emb", i32),
+                ("gated", i32), ("gelu", i32), ("remove_first", i32), ("tap_stride_cv", i32),
+                ("tap_stride_text", i32), ("tap_index", i32 * MAX_SIDE), ("first_index", i32)]
+
+
+class SasrecCfg(C.Structure):
+    _fields_ = [("seq", i32), ("emb", i32), ("heads", i32), ("blocks", i32), ("dropout", f32), ("seed", u64)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/iisan_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "iisan_version": (C.c_char_p, []),
+    "iisan_arch": (C.c_char_p, []),
+    "iisan_last_error": (C.c_char_p, []),
+    "iisan_vit_forward_taps_ws_bytes": (sz, [C.POINTER(VitWeights), i64, i64]),
+    "iisan_vit_forward_taps": (i32, [C.POINTER(VitWeights), vp, i64, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
+    "iisan_bert_forward_taps_ws_bytes": (sz, [C.POINTER(BertWeights), i64, i32, i64]),
+    "iisan_bert_forward_taps": (i32, [C.POINTER(BertWeights), vp, i64, i32, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
+    "iisan_side_net_ws_bytes": (sz, [C.POINTER(SideCfg), i64]),
+    "iisan_side_net_fwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
+    "iisan_side_net_bwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, C.POINTER(vp), vp, sz, vp]),
+    "iisan_linear_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_linear_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_sasrec_ws_bytes": (sz, [C.POINTER(SasrecCfg), i64]),
+    "iisan_sasrec_fwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
+    "iisan_sasrec_bwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, C.POINTER(vp), vp, sz, vp]),
+    "iisan_inbatch_ce_ws_bytes": (sz, [i64, i32]),
+    "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, sz, vp]),
+    "iisan_inbatch_ce_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "iisan_score_rank": (i32, [vp, vp, i64, i64, i32, vp, i32, vp, vp, vp]),
+    "iisan_adam_step": (i32, [vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(f32), i32, i32, f32, f32, f32, f32, vp]),
+    "iisan_gemm16": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_layernorm768": (i32, [i32, vp, vp, vp, f32, vp, vp, i64, vp]),
+    "iisan_attention16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_gemm32": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp]),
+    "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
+}
+
+_lib = None
+
+
+class IisanHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IisanHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C iisan_amd/csrc`).  There is no CPU fallback for the IISAN hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise IisanHipError(f"{what} failed (code {rc}): {load().iisan_last_error().decode()}")

@@ -1,0 +1,17 @@
+// Library-level entry points: version / arch / thread-local error string.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void iisan_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* iisan_version(void) { return "iisan_hip 0.1 (round 1)"; }
+extern "C" const char* iisan_arch(void) { return "gfx950"; }
+extern "C" const char* iisan_last_error(void) { return g_err; }

@@ -1,0 +1,160 @@
+// Internal helpers shared by the gfx950 kernels of libiisan_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/iisan_hip.h"
+
+// ---- vector types (wave64; MFMA operand fragments) ----------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ---- error plumbing ------------------------------------------------------------------------------------------
+void iisan_set_error(const char* fmt, ...);
+
+#define IISAN_CHECK_SHAPE(cond, ...)                                                                             \
+    do {                                                                                                         \
+        if (!(cond)) {                                                                                           \
+            iisan_set_error(__VA_ARGS__);                                                                        \
+            return IISAN_EBADSHAPE;                                                                              \
+        }                                                                                                        \
+    } while (0)
+
+#define IISAN_HIP_OK(expr)                                                                                       \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess) {                                                                                  \
+            iisan_set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, hipGetErrorString(_e));         \
+            return IISAN_EHIP;                                                                                   \
+        }                                                                                                        \
+    } while (0)
+
+#define IISAN_LAUNCH_OK() IISAN_HIP_OK(hipGetLastError())
+
+#define IISAN_TRY(expr)                                                                                          \
+    do {                                                                                                         \
+        int _r = (expr);                                                                                         \
+        if (_r != IISAN_OK) return _r;                                                                           \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over the caller's workspace (host side; the library never allocates device memory).
+struct WsCarver {
+    char* base;
+    size_t cap, off;
+    bool overflow;
+    WsCarver(void* p, size_t n) : base((char*)p), cap(n), off(0), overflow(false) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T), 256);
+        if (base && off + bytes > cap) overflow = true;
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+// ---- 16-bit operand type traits -------------------------------------------------------------------------------
+struct F16 {
+    typedef _Float16 elem;
+    typedef h8 v8;
+    typedef h4 v4;
+    static __device__ __forceinline__ f4 mfma(v8 a, v8 b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ elem from_f32(float x) { return (_Float16)x; }
+    static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+};
+struct BF16 {
+    typedef __bf16 elem;
+    typedef b8 v8;
+    typedef b4 v4;
+    static __device__ __forceinline__ f4 mfma(v8 a, v8 b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ elem from_f32(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+};
+
+// ---- device helpers ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu_erf
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16 (guide §5)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware bijective remap of a linear workgroup id: the dispatcher places id b on XCD b%8; give every XCD a
+// contiguous range of logical tiles so neighbouring tiles (sharing operand panels) hit the same L2 (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// internal launchers shared between translation units -----------------------------------------------------------
+struct Gemm16Args {
+    const void* A;      // [Mpad, K] 16-bit
+    const void* W;      // [N, K] 16-bit
+    const float* bias;  // [N] or null
+    void* out;          // mode-dependent
+    const float* resid; // fp32 [*, N] (modes 2,3)
+    const float* pos;   // patch mode: pos_emb [P+1, N]
+    int64_t M;          // valid rows
+    int32_t N, K;
+    int32_t lda, ldw, ldo;
+    int32_t patch_P;    // >0: row remap m -> (m/P)*(P+1) + 1 + m%P, += pos[1 + m%P]
+};
+enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3 };
+int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
+                        float* out32, int64_t rows, hipStream_t s);
+int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
+                       int heads, hipStream_t s);
+
+struct Gemm32Prob {
+    const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;
+    int64_t M; int32_t N; int64_t K;
+    int32_t lda, ldb, ldc, ldr;
+};
+// flags for launch_gemm32
+enum {
+    G32_TA = 1,        // A stored [K, M]
+    G32_TB = 2,        // B stored [K, N] (default [N, K], torch Linear weight)
+    G32_RELU = 4,      // C = relu(.)
+    G32_GELU = 8,      // C = gelu_erf(.)
+    G32_ACCUM = 16,    // C += (atomicAdd; enables split-K)
+    G32_MUL_RELU_MASK = 32,  // C = (.) * (act_src > 0)
+    G32_MUL_GELU_GRAD = 64,  // C = (.) * gelu'(act_src)
+    G32_PREACT = 128,  // also store the pre-activation into act_src (as float* out) -- fwd of GELU adapters
+};
+int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s);

@@ -1,0 +1,168 @@
+// Host-side executors of the two frozen encoders: enqueue the kernel chain of one ViT / BERT forward on the
+// caller's stream and write the per-layer CLS taps in one pass (no hidden state other than the live one is kept).
+// Replaces Vit_Encoder.forward / Bert_Encoder.forward + `hidden_states[i][:,0]`
+// (Code_Uncached/model/encoders.py:29-31,81-91,148-159; model.py:210-213) — and, run over a catalogue, what
+// Code_Cached/preprocess_vectors.py:68-112 precomputes.
+#include "common.h"
+
+int launch_vit_im2col(int dtype16, const float* img, void* out, int64_t M, int C, int R, int p, hipStream_t s);
+int launch_vit_cls_rows(float* X, const float* cls, const float* pos, int64_t M, int T, int D, hipStream_t s);
+int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, const float* pos, const float* type0,
+                         const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
+                         int W, int vocab, hipStream_t s);
+int launch_gather_cls(const float* X, float* taps, int64_t M, int T, int D, int n_taps, int k, hipStream_t s);
+
+namespace {
+
+struct EncBufs {
+    float* X;       // [Tp, D] fp32 residual stream
+    void* H;        // [Tp, D] 16-bit: LayerNorm output, reused as the attention context
+    void* QKV;      // [Tp, 3D] 16-bit
+    void* F1;       // [Tp, max(F, patch_dim)] 16-bit: GELU(FC1) (and the patch matrix during embedding)
+    float* KB;      // [Mc, W] key bias (BERT)
+};
+
+size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int D, int F, int64_t kb_elems) {
+    const int64_t Tp = ceil_div(tokens, 128) * 128;
+    b.X = c.take<float>((size_t)Tp * D);
+    b.H = c.take<uint16_t>((size_t)Tp * D);
+    b.QKV = c.take<uint16_t>((size_t)Tp * 3 * D);
+    b.F1 = c.take<uint16_t>((size_t)Tp * F);
+    b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
+    return c.off;
+}
+
+int gemm(int dt, int mode, const void* A, int K, const void* W, const float* bias, void* out, int N, const float* resid,
+         int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0) {
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = pos;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = patch_P;
+    return launch_gemm16(dt, mode, a, s);
+}
+
+int tap_index(const int32_t* tap_layers, int n, int layer) {
+    for (int k = 0; k < n; ++k)
+        if (tap_layers[k] == layer) return k;
+    return -1;
+}
+
+int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const int32_t* tap_layers) {
+    IISAN_CHECK_SHAPE(hidden == 768, "encoder hidden size must be 768 (got %d): the side network is 768 wide "
+                      "(Code_Uncached/model/model.py:171)", hidden);
+    IISAN_CHECK_SHAPE(heads > 0 && hidden == heads * 64, "encoder head_dim must be 64 (hidden %d, heads %d)", hidden, heads);
+    IISAN_CHECK_SHAPE(layers >= 1 && layers <= IISAN_MAX_LAYERS, "encoder layers %d out of range", layers);
+    IISAN_CHECK_SHAPE(mlp % 128 == 0, "encoder mlp size %d must be a multiple of 128", mlp);
+    IISAN_CHECK_SHAPE(n_taps >= 1 && tap_layers, "need at least one tap layer");
+    for (int k = 0; k < n_taps; ++k)
+        IISAN_CHECK_SHAPE(tap_layers[k] >= 0 && tap_layers[k] <= layers, "tap layer %d outside 0..%d", tap_layers[k], layers);
+    return IISAN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items) {
+    const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
+    const int P = (w->image / w->patch) * (w->image / w->patch);
+    const int pd = w->channels * w->patch * w->patch;
+    WsCarver c(nullptr, 0);
+    EncBufs b;
+    return carve(c, b, Mc * (P + 1), w->hidden, w->mlp > pd ? w->mlp : pd, 0);
+}
+
+extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* images, int64_t M,
+                                      const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_CHECK_SHAPE(M > 0, "vit_forward_taps: M must be positive");
+    IISAN_TRY(check_common(w->hidden, w->layers, w->heads, w->mlp, n_taps, tap_layers));
+    IISAN_CHECK_SHAPE(w->patch % 8 == 0 && w->image % w->patch == 0, "vit: patch %d / image %d unsupported", w->patch, w->image);
+    const int D = w->hidden, F = w->mlp, P = (w->image / w->patch) * (w->image / w->patch), T = P + 1;
+    const int pd = w->channels * w->patch * w->patch;
+    IISAN_CHECK_SHAPE(pd % 64 == 0, "vit: patch vector length %d must be a multiple of 64", pd);
+    IISAN_CHECK_SHAPE(T <= 224, "vit: %d tokens per image > 224 not supported", T);
+    const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
+    WsCarver c(ws, ws_bytes);
+    EncBufs b;
+    carve(c, b, Mc * T, D, F > pd ? F : pd, 0);
+    if (c.overflow || !ws) {
+        iisan_set_error("vit_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int dt = w->dtype16;
+    const int64_t img_elems = (int64_t)w->channels * w->image * w->image;
+    for (int64_t m0 = 0; m0 < M; m0 += Mc) {
+        const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;
+        const int64_t tok = mc * T;
+        float* tp = taps + m0 * n_taps * D;
+        IISAN_TRY(launch_vit_im2col(dt, images + m0 * img_elems, b.F1, mc, w->channels, w->image, w->patch, s));
+        IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));
+        IISAN_TRY(launch_vit_cls_rows(b.X, w->cls_token, w->pos_emb, mc, T, D, s));
+        int k = tap_index(tap_layers, n_taps, 0);
+        if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        for (int l = 0; l < w->layers; ++l) {
+            const iisan_layer_weights& L = w->layer[l];
+            // x += O(attn(LN1 x))
+            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln1_w, L.ln1_b, w->eps, b.H, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s));
+            IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
+            IISAN_TRY(gemm(dt, EPI_RESID32, b.H, D, L.o_w, L.o_b, b.X, D, b.X, tok, s));
+            // x += FC2(gelu(FC1(LN2 x)))
+            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln2_w, L.ln2_b, w->eps, b.H, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_RESID32, b.F1, F, L.fc2_w, L.fc2_b, b.X, D, b.X, tok, s));
+            k = tap_index(tap_layers, n_taps, l + 1);
+            if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        }
+    }
+    return IISAN_OK;
+}
+
+extern "C" size_t iisan_bert_forward_taps_ws_bytes(const iisan_bert_weights* w, int64_t M, int32_t words, int64_t chunk_items) {
+    const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
+    WsCarver c(nullptr, 0);
+    EncBufs b;
+    return carve(c, b, Mc * words, w->hidden, w->mlp, Mc * words);
+}
+
+extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, int64_t M, int32_t words,
+                                       const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
+                                       void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_CHECK_SHAPE(M > 0, "bert_forward_taps: M must be positive");
+    IISAN_TRY(check_common(w->hidden, w->layers, w->heads, w->mlp, n_taps, tap_layers));
+    IISAN_CHECK_SHAPE(words >= 1 && words <= w->max_pos && words <= 224, "bert: %d words unsupported", words);
+    const int D = w->hidden, F = w->mlp, T = words;
+    const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
+    WsCarver c(ws, ws_bytes);
+    EncBufs b;
+    carve(c, b, Mc * T, D, F, Mc * T);
+    if (c.overflow || !ws) {
+        iisan_set_error("bert_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int dt = w->dtype16;
+    for (int64_t m0 = 0; m0 < M; m0 += Mc) {
+        const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;
+        const int64_t tok = mc * T;
+        float* tp = taps + m0 * n_taps * D;
+        IISAN_TRY(launch_bert_embed_ln(dt, text + m0 * 2 * words, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_w,
+                                       w->emb_ln_b, w->eps, b.X, b.H, b.KB, mc, T, w->vocab, s));
+        int k = tap_index(tap_layers, n_taps, 0);
+        if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        for (int l = 0; l < w->layers; ++l) {
+            const iisan_layer_weights& L = w->layer[l];
+            // a = LN(x + O(attn(x)))
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s));
+            IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
+            IISAN_TRY(gemm(dt, EPI_RESID32, b.H, D, L.o_w, L.o_b, b.X, D, b.X, tok, s));
+            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln1_w, L.ln1_b, w->eps, b.H, b.X, tok, s));
+            // x = LN(a + FC2(gelu(FC1 a)))
+            IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_RESID32, b.F1, F, L.fc2_w, L.fc2_b, b.X, D, b.X, tok, s));
+            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln2_w, L.ln2_b, w->eps, b.H, b.X, tok, s));
+            k = tap_index(tap_layers, n_taps, l + 1);
+            if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        }
+    }
+    return IISAN_OK;
+}

@@ -1,0 +1,191 @@
+// 16-bit-operand MFMA GEMM of the frozen encoders:  C = epilogue(A[M,K] · W[N,K]^T + bias), fp32 accumulate.
+//
+// This is where ≈96 % of the hot path's FLOPs go (QKV, O, FC1, FC2 and the patch-embedding
+// conv-as-GEMM).  Roofline: bf16/f16 MFMA (2.5 PFLOP/s dense).  Structure (gfx950):
+//   * 128x128x64 tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 fragments of
+//     v_mfma_f32_16x16x32), two workgroups per CU;
+//   * both operand tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR round trip), double buffered:
+//     the DMA of K-tile t+1 is in flight while tile t feeds the MFMAs, one vmcnt(0)+barrier per K-tile;
+//   * LDS tiles are row-major with 128-byte rows; 16-byte slots are XOR-swizzled with (row & 7) so the
+//     ds_read_b128 fragment reads are bank-conflict free.  The DMA destination is lane-linear, so the swizzle is
+//     applied to the per-lane SOURCE address and again on the read (guide §5.4 rule 21);
+//   * operands are swapped in the MFMA (W rows as the "A" operand) and W rows are permuted while staging, so each
+//     lane ends up with 8 CONSECUTIVE output columns of one row -> 16-byte (16-bit out) / 2x16-byte (fp32 out)
+//     epilogue stores, bias/residual/GELU/position-embedding fused;
+//   * logical tile ids are remapped per XCD so co-resident workgroups share A row panels in their L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + W
+
+// LDS row q of the W tile holds W row n0 + nperm(q): accumulator register r of fragment a (0/1) in a 32-column
+// block then lands on column 8*(lane>>4) + 4*a + r.
+__device__ __forceinline__ int nperm(int q) { return (q & ~31) + 8 * ((q & 15) >> 2) + 4 * ((q >> 4) & 1) + (q & 3); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
+    typedef typename T::v8 V8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_n = p.N / BN;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const char* Ag = (const char*)p.A + m0 * p.lda * 2;
+    const char* Wg = (const char*)p.W + (int64_t)n0 * p.ldw * 2;
+
+    // staging: chunk c = wave*4+j covers LDS rows 8c..8c+7 (1 KiB); lane -> row q = 8c + (lane>>3), physical
+    // 16-byte slot lane&7, which must hold logical slot (lane&7) ^ (q&7).
+    int64_t a_off[4], w_off[4];
+    {
+        const int slog = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = (wave * 4 + j) * 8 + (lane >> 3);
+            a_off[j] = (int64_t)q * p.lda * 2 + slog * 16;
+            w_off[j] = (int64_t)nperm(q) * p.ldw * 2 + slog * 16;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+        char* sW = sA + TILE_BYTES;
+        const int64_t kb = (int64_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(Ag + a_off[j] + kb, sA + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(Wg + w_off[j] + kb, sW + j * 1024);
+    };
+
+    f4 acc[4][2][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[b][nb][a] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read addresses: row = base + (lane&15) (so row&7 == lane&7), logical slot = kk*4 + (lane>>4)
+    const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+    const int xrow_off = (wave_m * 64 + frow) * 128;
+    const int wrow_off = (wave_n * 64 + frow) * 128;
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* sA = smem + cur * STAGE_BYTES;
+        const char* sW = sA + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = ((kk * 4 + fg) ^ fsw) << 4;
+            V8 xf[4], wf[2][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[b] = *(const V8*)(sA + xrow_off + b * 2048 + slot);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[nb][a] = *(const V8*)(sW + wrow_off + (nb * 32 + a * 16) * 128 + slot);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) acc[b][nb][a] = T::mfma(wf[nb][a], xf[b], acc[b][nb][a]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (j = lane&15, g = lane>>4) owns row m0+wave_m*64+b*16+j, columns n..n+7 -----------------
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t m = m0 + wave_m * 64 + b * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n = n0 + wave_n * 64 + nb * 32 + 8 * fg;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[b][nb][0][r];
+                v[4 + r] = acc[b][nb][1][r];
+            }
+            if (p.bias) {
+                const f4 b0 = *(const f4*)(p.bias + n), b1 = *(const f4*)(p.bias + n + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += b0[r];
+                    v[4 + r] += b1[r];
+                }
+            }
+            if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16) {
+                V8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = T::from_f32(EPI == EPI_GELU16 ? gelu_erf(v[r]) : v[r]);
+                *(V8*)((typename T::elem*)p.out + m * p.ldo + n) = o;
+            } else if constexpr (EPI == EPI_RESID32) {
+                const float* rp = p.resid + m * p.ldo + n;
+                const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
+                float* op = (float*)p.out + m * p.ldo + n;
+                *(f4*)op = (f4){v[0] + r0[0], v[1] + r0[1], v[2] + r0[2], v[3] + r0[3]};
+                *(f4*)(op + 4) = (f4){v[4] + r1[0], v[5] + r1[1], v[6] + r1[2], v[7] + r1[3]};
+            } else {  // EPI_PATCH32: patch row m of image m/P -> token row img*(P+1)+1+m%P, + position embedding
+                const int64_t img = m / p.patch_P;
+                const int pp = (int)(m - img * p.patch_P);
+                const float* pe = p.pos + (int64_t)(1 + pp) * p.N + n;
+                const f4 r0 = *(const f4*)pe, r1 = *(const f4*)(pe + 4);
+                float* op = (float*)p.out + (img * (p.patch_P + 1) + 1 + pp) * p.ldo + n;
+                *(f4*)op = (f4){v[0] + r0[0], v[1] + r0[1], v[2] + r0[2], v[3] + r0[3]};
+                *(f4*)(op + 4) = (f4){v[4] + r1[0], v[5] + r1[1], v[6] + r1[2], v[7] + r1[3]};
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
+    const int64_t tiles = ceil_div(a.M, BM) * (a.N / BN);
+    dim3 grid((unsigned)tiles), block(256);
+    switch (mode) {
+        case EPI_OUT16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_OUT16>), grid, block, 0, s, a); break;
+        case EPI_GELU16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_GELU16>), grid, block, 0, s, a); break;
+        case EPI_RESID32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_RESID32>), grid, block, 0, s, a); break;
+        case EPI_PATCH32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH32>), grid, block, 0, s, a); break;
+        default: iisan_set_error("gemm16: bad epilogue mode %d", mode); return IISAN_EBADSHAPE;
+    }
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+}  // namespace
+
+int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
+    IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0, "gemm16: empty problem M=%lld N=%d K=%d", (long long)a.M, a.N, a.K);
+    IISAN_CHECK_SHAPE(a.N % BN == 0 && a.K % BK == 0, "gemm16: N (%d) must be a multiple of %d and K (%d) of %d", a.N, BN, a.K, BK);
+    IISAN_CHECK_SHAPE(ceil_div(a.M, BM) * (a.N / BN) < (1ll << 31), "gemm16: grid too large");
+    IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
+    IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
+    return dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+}
+
+extern "C" int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,
+                            const float* resid, int64_t M, int32_t N, int32_t K, void* stream) {
+    IISAN_CHECK_SHAPE(mode >= 0 && mode <= 2, "iisan_gemm16: mode must be 0, 1 or 2");
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = 0;
+    return launch_gemm16(dtype16, mode, a, (hipStream_t)stream);
+}

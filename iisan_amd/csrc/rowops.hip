@@ -1,0 +1,222 @@
+// Row-wise HBM-bound kernels of the frozen encoders: LayerNorm, patch extraction, embedding gather, CLS taps.
+// Roofline: HBM (one read + one write of each row); one wave64 per 768-wide row, 16-byte lane accesses,
+// wavefront-shuffle reductions, fp32 statistics (two-pass mean / centred variance in registers).
+#include "common.h"
+
+namespace {
+
+// ---- LayerNorm over rows of 768 fp32 (HF nn.LayerNorm, eps inside the sqrt) ------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ b, float eps,
+                                                           typename T::elem* __restrict__ out16,
+                                                           float* __restrict__ out32, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * 768;
+    f4 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] = *(const f4*)(xr + i * 256 + lane * 4);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / 768.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 768.0f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f4 gg = *(const f4*)(g + c), bb = *(const f4*)(b + c);
+        f4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+        if (out32) *(f4*)(out32 + row * 768 + c) = y;
+        if (out16) {
+            typename T::v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = T::from_f32(y[e]);
+            *(typename T::v4*)(out16 + row * 768 + c) = o;
+        }
+    }
+}
+
+// ---- ViT patch extraction: images fp32 [M,C,R,R] -> patch matrix 16-bit [M*P, C*p*p], col = c*p*p + iy*p + ix ----
+// one thread = 8 consecutive ix (two float4 reads, one 16-byte store)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_im2col_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out,
+                                                         int64_t M, int C, int R, int p) {
+    const int per_row = C * p * p / 8;        // threads per patch row
+    const int gp = R / p;                      // patches per image side
+    const int64_t total = M * gp * gp * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % per_row);
+        const int64_t pr = i / per_row;        // patch row index = m*P + py*gp + px
+        const int col = t * 8;
+        const int c = col / (p * p), rem = col % (p * p), iy = rem / p, ix = rem % p;
+        const int64_t m = pr / (gp * gp);
+        const int pp = (int)(pr % (gp * gp)), py = pp / gp, px = pp % gp;
+        const float* src = img + ((m * C + c) * R + (py * p + iy)) * (int64_t)R + px * p + ix;
+        const f4 a = *(const f4*)src, b2 = *(const f4*)(src + 4);
+        typename T::v8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = T::from_f32(a[e]);
+            o[4 + e] = T::from_f32(b2[e]);
+        }
+        *(typename T::v8*)(out + pr * (int64_t)(C * p * p) + col) = o;
+    }
+}
+
+// CLS rows of the token matrix: X[m*T] = cls + pos[0]
+__global__ void vit_cls_rows_kernel(float* __restrict__ X, const float* __restrict__ cls, const float* __restrict__ pos,
+                                    int64_t M, int T, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * D) return;
+    const int64_t m = i / D;
+    const int d = (int)(i % D);
+    X[m * T * D + d] = cls[d] + pos[d];
+}
+
+// ---- BERT embeddings: LN(word[id] + pos[t] + type[0]) -> X fp32 + H 16-bit; key bias from the attention mask ------
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __restrict__ text, const float* __restrict__ word,
+                                                            const float* __restrict__ pos, const float* __restrict__ type0,
+                                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                            float* __restrict__ X, typename T::elem* __restrict__ H,
+                                                            float* __restrict__ key_bias, int64_t M, int W, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M * W) return;
+    const int64_t m = row / W;
+    const int t = (int)(row % W);
+    int64_t id = text[m * 2 * W + t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    if (lane == 0) key_bias[row] = text[m * 2 * W + W + t] != 0 ? 0.0f : -1.0f;
+    const float* wr = word + id * 768;
+    const float* pr = pos + (int64_t)t * 768;
+    f4 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f4 a = *(const f4*)(wr + c), p2 = *(const f4*)(pr + c), ty = *(const f4*)(type0 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = a[e] + p2[e] + ty[e];
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / 768.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 768.0f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f4 gg = *(const f4*)(g + c), bb = *(const f4*)(b + c);
+        f4 y;
+        typename T::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            o[e] = T::from_f32(y[e]);
+        }
+        *(f4*)(X + row * 768 + c) = y;
+        *(typename T::v4*)(H + row * 768 + c) = o;
+    }
+}
+
+// taps[m, k, :] = X[m*T, :]   (CLS row of every item; Code_Uncached/model/model.py:212-213)
+__global__ void gather_cls_kernel(const float* __restrict__ X, float* __restrict__ taps, int64_t M, int T, int D,
+                                  int n_taps, int k) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
+    const int d4 = D / 4;
+    if (i >= M * d4) return;
+    const int64_t m = i / d4;
+    const int c = (int)(i % d4) * 4;
+    *(f4*)(taps + (m * n_taps + k) * D + c) = *(const f4*)(X + m * T * D + c);
+}
+
+template <typename T>
+__global__ void cast16_kernel(const float* __restrict__ src, typename T::elem* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = T::from_f32(src[i]);
+}
+
+}  // namespace
+
+int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
+                        float* out32, int64_t rows, hipStream_t s) {
+    if (rows <= 0) return IISAN_OK;
+    dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+    if (dtype16 == IISAN_BF16)
+        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, g, b, eps, (__bf16*)out16, out32, rows);
+    else
+        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, g, b, eps, (_Float16*)out16, out32, rows);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_vit_im2col(int dtype16, const float* img, void* out, int64_t M, int C, int R, int p, hipStream_t s) {
+    const int64_t total = M * (R / p) * (R / p) * (C * p * p / 8);
+    const unsigned grid = (unsigned)(ceil_div(total, 256) < 262144 ? ceil_div(total, 256) : 262144);
+    if (dtype16 == IISAN_BF16)
+        hipLaunchKernelGGL(vit_im2col_kernel<BF16>, dim3(grid), dim3(256), 0, s, img, (__bf16*)out, M, C, R, p);
+    else
+        hipLaunchKernelGGL(vit_im2col_kernel<F16>, dim3(grid), dim3(256), 0, s, img, (_Float16*)out, M, C, R, p);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_vit_cls_rows(float* X, const float* cls, const float* pos, int64_t M, int T, int D, hipStream_t s) {
+    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3((unsigned)ceil_div(M * D, 256)), dim3(256), 0, s, X, cls, pos, M, T, D);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, const float* pos, const float* type0,
+                         const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
+                         int W, int vocab, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(M * W, 4)), block(256);
+    if (dtype16 == IISAN_BF16)
+        hipLaunchKernelGGL(bert_embed_ln_kernel<BF16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (__bf16*)H, key_bias, M, W, vocab);
+    else
+        hipLaunchKernelGGL(bert_embed_ln_kernel<F16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (_Float16*)H, key_bias, M, W, vocab);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_gather_cls(const float* X, float* taps, int64_t M, int T, int D, int n_taps, int k, hipStream_t s) {
+    hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)ceil_div(M * (D / 4), 256)), dim3(256), 0, s, X, taps, M, T, D, n_taps, k);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+extern "C" int iisan_layernorm768(int32_t dtype16, const float* x, const float* g, const float* b, float eps,
+                                  void* out16, float* out32, int64_t rows, void* stream) {
+    return launch_layernorm768(dtype16, x, g, b, eps, out16, out32, rows, (hipStream_t)stream);
+}
+
+extern "C" int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_t n, void* stream) {
+    if (n <= 0) return IISAN_OK;
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 65536 ? ceil_div(n, 256) : 65536);
+    if (dtype16 == IISAN_BF16)
+        hipLaunchKernelGGL(cast16_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+    else
+        hipLaunchKernelGGL(cast16_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}

@@ -1,0 +1,215 @@
+/*
+ * iisan_hip.h — C ABI of libiisan_hip.so: the MI355X (gfx950) implementation of IISAN's data-parallel hot path.
+ *
+ * The reference (GAIR-Lab/IISAN) has no FFI: its "operator interface" for this path is the Python nn.Module
+ * surface of the Code_Uncached and Code_Cached model/ packages.  Each entry point below replaces the arithmetic of one reference
+ * forward (or the autograd backward PyTorch derives from it); the reference lines are cited per function.
+ * `iisan_amd/` binds these with ctypes behind modules of the same names.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to row-major contiguous memory owned by the caller (16-byte aligned),
+ *     except arguments documented as "host";
+ *   - the library never allocates device memory, never synchronises and never owns buffers: scratch comes in
+ *     through `ws`/`ws_bytes`, sized by the matching *_ws_bytes() query;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); functions are re-entrant per stream;
+ *   - return 0 on success, IISAN_EBADSHAPE / IISAN_EWORKSPACE / IISAN_EHIP (<0) otherwise, with a message in
+ *     iisan_last_error() (thread local);
+ *   - `dtype16` selects the 16-bit MFMA operand type of the frozen encoders: IISAN_F16 (default; the reference
+ *     itself runs them under fp16 autocast, Code_Uncached/run.py:409) or IISAN_BF16.  Accumulation, the
+ *     residual stream, LayerNorm/softmax statistics, taps and everything trainable are fp32.
+ */
+#ifndef IISAN_HIP_H
+#define IISAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IISAN_OK 0
+#define IISAN_EBADSHAPE (-1)
+#define IISAN_EWORKSPACE (-2)
+#define IISAN_EHIP (-3)
+
+#define IISAN_F16 0
+#define IISAN_BF16 1
+
+#define IISAN_MAX_LAYERS 48
+#define IISAN_MAX_SIDE 16
+
+const char* iisan_version(void);
+const char* iisan_arch(void);            /* "gfx950" */
+const char* iisan_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Frozen encoders (no-grad).  Weights are packed once by the host (iisan_amd/encoders.py): matrices in the 16-bit
+ * operand type, [out,in] row-major exactly like torch.nn.Linear.weight; vectors in fp32.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* qkv_w;  const float* qkv_b;   /* [3D,D] 16-bit, [3D]  (q;k;v stacked)                          */
+    const void* o_w;    const float* o_b;     /* [D,D], [D]                                                     */
+    const void* fc1_w;  const float* fc1_b;   /* [F,D], [F]                                                     */
+    const void* fc2_w;  const float* fc2_b;   /* [D,F], [D]                                                     */
+    const float* ln1_w; const float* ln1_b;   /* ViT: layernorm_before;  BERT: attention.output.LayerNorm       */
+    const float* ln2_w; const float* ln2_b;   /* ViT: layernorm_after;   BERT: output.LayerNorm                 */
+} iisan_layer_weights;
+
+typedef struct {
+    int32_t hidden, layers, heads, mlp;       /* D, L, H, F                                                     */
+    int32_t image, patch, channels;           /* 224, 16, 3                                                     */
+    int32_t dtype16;
+    float   eps;
+    const void*  patch_w;                     /* [D, C*P*P] 16-bit (Conv2d kernel flattened (c,py,px))          */
+    const float* patch_b;                     /* [D]                                                            */
+    const float* cls_token;                   /* [D]                                                            */
+    const float* pos_emb;                     /* [T, D], T = (image/patch)^2 + 1                                */
+    iisan_layer_weights layer[IISAN_MAX_LAYERS];
+} iisan_vit_weights;
+
+typedef struct {
+    int32_t hidden, layers, heads, mlp;
+    int32_t vocab, max_pos;
+    int32_t dtype16;
+    float   eps;
+    const float* word_emb;                    /* [V, D] fp32 (gather only)                                      */
+    const float* pos_emb;                     /* [max_pos, D]                                                   */
+    const float* type_emb;                    /* [2, D] (row 0 used)                                            */
+    const float* emb_ln_w; const float* emb_ln_b;
+    iisan_layer_weights layer[IISAN_MAX_LAYERS];
+} iisan_bert_weights;
+
+/* Replaces Vit_Encoder.forward + `[:,0]` tap selection (Code_Uncached/model/encoders.py:29-31, model.py:210,212):
+ * images fp32 [M,C,R,R] -> taps fp32 [M, n_taps, D], taps[:,k] = CLS row of hidden state tap_layers[k]
+ * (0 = embeddings, l = output of layer l; the last one is before the final LayerNorm).  `tap_layers` is a host
+ * array.  `chunk_items` (0 = whole batch) bounds the activation working set. */
+size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items);
+int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* images, int64_t M,
+                           const int32_t* tap_layers, int32_t n_taps, float* taps,
+                           int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
+
+/* Replaces Text_Encoder/Bert_Encoder.forward + tap selection (encoders.py:81-91,148-159, model.py:211,213):
+ * text int64 [M, 2W] (W ids then W attention-mask values) -> taps fp32 [M, n_taps, D]. */
+size_t iisan_bert_forward_taps_ws_bytes(const iisan_bert_weights* w, int64_t M, int32_t words, int64_t chunk_items);
+int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, int64_t M, int32_t words,
+                            const int32_t* tap_layers, int32_t n_taps, float* taps,
+                            int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Side network (IISANAdaptedMModel.forward, Code_Uncached/model/model.py:209-271; Cached model.py:300-349).
+ * All fp32.  Parameters arrive as a host array of device pointers in the order documented at
+ * iisan_amd/ops.py::SIDE_PARAM_ORDER:
+ *   for tower in (cv, text, mm): for k in 0..n_side-1: fc_down.weight, fc_down.bias, fc_up.weight, fc_up.bias
+ *   gates: cv[0..n), text[0..n), mm[0..n)      (each a 1-element tensor; ignored when gated == 0)
+ *   fc_cv.w, fc_cv.b, fc_bert.w, fc_bert.b, fc_mm.w, fc_mm.b,
+ *   head_cv.w, head_cv.b (classifier / cv_pre_fc), head_text.w, head_text.b (title.fc / bert_pre_fc),
+ *   fc_mm_down.w, fc_mm_down.b
+ * Gradients are written to a parallel host array of device pointers (same order), ACCUMULATING (+=) into them;
+ * the caller zeroes them.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_side;           /* number of SANBs per tower (7; 6 with remove_first)                             */
+    int32_t dim_cv, dim_text; /* tap widths (768, 768)                                                          */
+    int32_t down;             /* adapter bottleneck (64)                                                        */
+    int32_t emb;              /* embedding_dim (64)                                                             */
+    int32_t gated;            /* fusion_method == "gated"                                                       */
+    int32_t gelu;             /* adapter_activation == "GELU"                                                   */
+    int32_t remove_first;     /* args.remove_first == "TRUE": states start at taps[:,0] (model.py:215-218)      */
+    int32_t tap_stride_cv;    /* taps are [M, tap_stride, D]; tap_index[k] selects the layer of SANB k          */
+    int32_t tap_stride_text;
+    int32_t tap_index[IISAN_MAX_SIDE];     /* index along the tap axis used by SANB k                          */
+    int32_t first_index;                   /* tap index that seeds the states when remove_first                */
+} iisan_side_cfg;
+
+size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M);        /* saved activations + scratch    */
+/* out: item3 fp32 [M, 3*emb] = cat[cv, text, mm] (the com_dense input, model.py:69) */
+int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
+                       const void* const* params, float* item3, void* ws, size_t ws_bytes, void* stream);
+int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
+                       const void* const* params, const float* d_item3, void* const* grads,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Plain fp32 Linear (com_dense, Code_Uncached/model/model.py:36-37,69): y = x W^T + b ; bwd accumulates dW, db.
+ * ---------------------------------------------------------------------------------------------------------- */
+int iisan_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int32_t K, int32_t N,
+                     void* stream);
+int iisan_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                     int64_t M, int32_t K, int32_t N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SASRec user encoder (User_Encoder.forward, Code_Uncached/model/encoders.py:60-65; modules.py:6-96).  fp32.
+ * params order (host array of device pointers): position_embedding.weight, layer_norm.{weight,bias}, then per
+ * block: w_Q, w_K, w_V, fc (weights), attn layer_norm.{weight,bias}, w_1.{weight,bias}, w_2.{weight,bias},
+ * ffn layer_norm.{weight,bias}.   x: [B,S,E]; log_mask: [B,S]; y: [B,S,E].
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t seq, emb, heads, blocks;       /* 10, 64, 2, 2                                                     */
+    float   dropout;                        /* 0 => identity (eval)                                             */
+    uint64_t seed;                          /* dropout stream (ignored when dropout == 0)                       */
+} iisan_sasrec_cfg;
+
+size_t iisan_sasrec_ws_bytes(const iisan_sasrec_cfg* cfg, int64_t B);
+int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B,
+                     const void* const* params, float* y, void* ws, size_t ws_bytes, void* stream);
+int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B,
+                     const void* const* params, const float* dy, float* dx, void* const* grads,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * In-batch debiased cross-entropy (ModelMM.forward, Code_Uncached/model/model.py:81-104), fused: the [T,M]
+ * logits are never materialised.  ids int64 [bs*(S+1)], score fp32 [bs*(S+1),E], prec fp32 [bs*S,E],
+ * log_mask fp32 [bs,S], pop_prob fp32 [item_num+1].  loss: 1 float.  row_lse: [bs*S] scratch kept for bwd.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S);
+int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
+                         const float* pop_prob, int64_t bs, int32_t S, int32_t E, float* loss,
+                         void* ws, size_t ws_bytes, void* stream);
+/* d_loss: host scalar multiplier (upstream gradient).  d_score [M,E] and d_prec [T,E] are overwritten. */
+int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
+                         const float* pop_prob, int64_t bs, int32_t S, int32_t E, float d_loss,
+                         float* d_score, float* d_prec, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Eval scoring (eval_model + metrics_topK, Code_Uncached/data_utils/metrics.py:59-67,198-207): for each user
+ * the 1-based rank of `target` among items 1..item_num by score = prec . item_emb, history scored -inf, ties
+ * towards the lower item id.  history: int32 [U, hist_stride] padded with 0.  ranks: int32 [U].
+ * ---------------------------------------------------------------------------------------------------------- */
+int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
+                     const int32_t* history, int32_t hist_stride, const int32_t* target, int32_t* ranks,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused Adam over a flat fp32 parameter buffer with per-segment learning rates (torch.optim.Adam defaults, the
+ * optimiser of Code_Uncached/run.py:323-336).  seg_end (host, int64[n_seg]) are exclusive end offsets.
+ * ---------------------------------------------------------------------------------------------------------- */
+int iisan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
+                    const float* seg_lr, int32_t n_seg, int32_t step, float beta1, float beta2, float eps,
+                    float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Primitive kernels, exported for unit tests and micro-benchmarks only.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* C = epilogue(A[M,K] · W[N,K]^T + bias): 16-bit operands, fp32 accumulate.
+ * mode 0: out16 = acc+bias     1: out16 = gelu_erf(acc+bias)     2: out32 = acc+bias+resid32 (resid may alias out) */
+int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,
+                 const float* resid, int64_t M, int32_t N, int32_t K, void* stream);
+/* LayerNorm over rows of width 768: out16 (nullable) / out32 (nullable) */
+int iisan_layernorm768(int32_t dtype16, const float* x, const float* g, const float* b, float eps,
+                       void* out16, float* out32, int64_t rows, void* stream);
+/* softmax(QK^T/sqrt(64) + key_bias)V per (item, head); qkv 16-bit [items*S, 3*H*64]; ctx 16-bit [items*S, H*64];
+ * key_bias fp32 [items,S] or NULL (values < 0 mark masked keys) */
+int iisan_attention16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int32_t S,
+                      int32_t heads, void* stream);
+/* fp32 MFMA GEMM: C[M,N] = op(A) op(B) (+bias)(+relu); ta: A stored [K,M]; tb: B stored [K,N] (else [N,K]);
+ * accumulate != 0: C += (atomic, split-K capable) */
+int iisan_gemm32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
+                 int32_t ta, int32_t tb, int32_t relu, int32_t accumulate, void* stream);
+/* f32 -> 16-bit conversion helper used when packing weights */
+int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IISAN_HIP_H */

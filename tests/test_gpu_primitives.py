@@ -1,0 +1,120 @@
+"""GPU unit tests of the primitive HIP kernels (called through the C ABI) against plain PyTorch fp32 on the CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from iisan_amd import _lib  # noqa: E402
+
+T16 = {0: torch.float16, 1: torch.bfloat16}
+TOL = {0: 2e-3, 1: 1.6e-2}       # relative to the output scale: one 16-bit rounding of the result
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad_rows(t, mult=128):
+    M = t.shape[0]
+    Mp = (M + mult - 1) // mult * mult
+    out = torch.zeros((Mp,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[:M] = t
+    return out
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1000, 768, 3072), (517, 2304, 768)])
+def test_gemm16_vs_torch(lib, dt, mode, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N + K + mode)
+    # asymmetric, non-identity operands (catches transposed / permuted fragment layouts)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(T16[dt])
+    W = (torch.randn(N, K, generator=g) * 0.05 + torch.linspace(-0.02, 0.03, N)[:, None]).to(T16[dt])
+    bias = torch.randn(N, generator=g) * 0.3
+    resid = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    if mode == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if mode == 2:
+        ref = ref + resid.double()
+    Ad, Wd, bd = _pad_rows(A.cuda()), W.cuda(), bias.cuda()
+    if mode == 2:
+        out = resid.cuda().clone()            # in-place residual, as the encoders use it
+        rp = out
+    else:
+        out = torch.empty(M, N, dtype=T16[dt], device="cuda")
+        rp = None
+    _lib.check(lib.iisan_gemm16(dt, mode, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                rp.data_ptr() if rp is not None else None, M, N, K, _stream()), "gemm16")
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    tol = (2e-5 if mode == 2 else TOL[dt]) * scale
+    assert err <= tol, f"gemm16 dt={dt} mode={mode} {shape}: max err {err:.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_layernorm768_vs_torch(lib, dt):
+    g = torch.Generator().manual_seed(3)
+    rows = 1001
+    x = torch.randn(rows, 768, generator=g) * 3 + 0.7
+    w = 1 + 0.1 * torch.randn(768, generator=g)
+    b = 0.1 * torch.randn(768, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (768,), w.double(), b.double(), 1e-12)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()      # keep the device tensors alive across the launch
+    o16 = torch.empty(rows, 768, dtype=T16[dt], device="cuda")
+    o32 = torch.empty(rows, 768, dtype=torch.float32, device="cuda")
+    _lib.check(lib.iisan_layernorm768(dt, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 1e-12,
+                                      o16.data_ptr(), o32.data_ptr(), rows, _stream()), "layernorm768")
+    torch.cuda.synchronize()
+    assert (o32.cpu().double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item() + 1e-5
+    assert (o16.cpu().double() - ref).abs().max().item() < TOL[dt] * ref.abs().max().item()
+    # in-place fp32 output (BERT post-LN residual stream)
+    _lib.check(lib.iisan_layernorm768(dt, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 1e-12,
+                                      None, xd.data_ptr(), rows, _stream()), "layernorm768 in place")
+    torch.cuda.synchronize()
+    assert (xd.cpu().double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item() + 1e-5
+
+
+def _attn_ref(qkv, key_bias, items, S, heads):
+    D = heads * 64
+    x = qkv.double().view(items, S, 3, heads, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if key_bias is not None:
+        masked = (key_bias < 0)[:, None, None, :]
+        s = torch.where(masked, torch.full_like(s, torch.finfo(torch.float32).min), s)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(items * S, D)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", [(3, 197, 12, False), (5, 30, 12, True), (4, 5, 12, False), (3, 8, 2, True),
+                                  (2, 64, 3, False), (2, 100, 2, True)])
+def test_attention16_vs_torch(lib, dt, case):
+    items, S, heads, masked = case
+    g = torch.Generator().manual_seed(S * 13 + heads)
+    D = heads * 64
+    qkv = (torch.randn(items * S, 3 * D, generator=g) * 1.5).to(T16[dt])
+    kb = None
+    if masked:
+        kb = torch.zeros(items, S)
+        for i in range(items):
+            n = int(torch.randint(1, S + 1, (1,), generator=g))
+            kb[i, n:] = -1.0
+        kb[0, :] = -1.0                       # an all-masked (padding) item attends uniformly
+    ref = _attn_ref(qkv, kb, items, S, heads)
+    ctx = torch.empty(items * S, D, dtype=T16[dt], device="cuda")
+    kbd = kb.cuda() if kb is not None else None
+    qkvd = qkv.cuda()
+    _lib.check(lib.iisan_attention16(dt, qkvd.data_ptr(), kbd.data_ptr() if kbd is not None else None,
+                                     ctx.data_ptr(), items, S, heads, _stream()), "attention16")
+    torch.cuda.synchronize()
+    err = (ctx.cpu().double() - ref).abs().max().item()
+    tol = 2.5 * TOL[dt] * ref.abs().max().item()     # P and O are both rounded to 16 bit
+    assert err <= tol, f"attention dt={dt} {case}: max err {err:.3e} > {tol:.3e}"
