@@ -1,0 +1,329 @@
+// Fused in-batch debiased cross-entropy (forward + backward) — the [T, M] logits matrix is never materialised.
+// Replaces the loss section of ModelMM.forward (Code_Uncached/model/model.py:81-104), including its O(bs)
+// Python masking loop (model.py:92-100) whose autograd graph dominates the reference's Cached step at bs=1024
+// (SURVEY.md §3.2).  Exact semantics kept, in the reference's order:
+//     z[row,c]  = prec[row]·score[c] - log pop[id_c]
+//     z[:,c]    = -1e4   if slot c is history padding (position < S and log_mask == 0)            (model.py:88-89)
+//     z[row,c]  = -1e4   if id_c occurs in the row's own sequence and c is not the row's positive  (model.py:92-100)
+//     loss      = mean over rows with log_mask != 0 of  logsumexp(z[row,:]) - z[row, label]       (model.py:102-104)
+//
+// One workgroup owns 16 rows of X (prec rows for fwd / d_prec, score rows for d_score) and streams the other
+// matrix in 16-row tiles, four waves taking tiles round-robin.  Logit tiles are computed TRANSPOSED on the f32
+// matrix cores (v_mfma_f32_16x16x4_f32, K = E = 64) so a lane owns one X row and 4 Y columns per tile: the online
+// log-sum-exp is per-lane + two xor-shuffles, and the dZ registers are already the B operand of the second product
+// dX^T = Y^T·dZ^T.  The Y tile is staged once per wave in LDS (272-byte rows: conflict-free ds_read_b128).
+#include "common.h"
+
+namespace {
+
+constexpr int E = 64;
+constexpr int YLD = 68;           // padded LDS row (floats)
+constexpr float MASKV = -1e4f;
+
+struct CeBufs {
+    int* ids32;      // [M]
+    float* debias;   // [M] log pop[id]
+    int* colpad;     // [M] 1 if the slot is history padding
+    float* lse;      // [T]
+    float* rowloss;  // [T]
+    float* nvalid;   // [1]
+};
+
+void carve(WsCarver& c, CeBufs& b, int64_t bs, int S) {
+    const size_t M = (size_t)bs * (S + 1), T = (size_t)bs * S;
+    b.ids32 = c.take<int>(M);
+    b.debias = c.take<float>(M);
+    b.colpad = c.take<int>(M);
+    b.lse = c.take<float>(T);
+    b.rowloss = c.take<float>(T);
+    b.nvalid = c.take<float>(4);
+}
+
+__global__ void ce_prep_kernel(const int64_t* __restrict__ ids, const float* __restrict__ log_mask,
+                               const float* __restrict__ pop, CeBufs b, int64_t bs, int S) {
+    const int64_t M = bs * (S + 1);
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = c / (S + 1);
+        const int p = (int)(c - i * (S + 1));
+        const int64_t id = ids[c];
+        b.ids32[c] = (int)id;
+        b.debias[c] = logf(pop[id]);
+        b.colpad[c] = (p < S && log_mask[i * S + p] == 0.f) ? 1 : 0;
+    }
+}
+
+// n_valid = #{log_mask != 0}; single block, fixed order
+__global__ __launch_bounds__(256) void ce_count_kernel(const float* __restrict__ log_mask, int64_t T, float* out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < T; i += 256) s += log_mask[i] != 0.f ? 1.f : 0.f;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ rowloss, int64_t T, const float* nvalid,
+                                                        float* loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < T; i += 256) s += rowloss[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / nvalid[0];
+}
+
+__device__ __forceinline__ bool id_in_seq(const int* __restrict__ ids32, int64_t seq, int S1, int idc) {
+    bool hit = false;
+    for (int p = 0; p < S1; ++p) hit |= ids32[seq * S1 + p] == idc;
+    return hit;
+}
+
+enum { CE_FWD = 0, CE_DPREC = 1, CE_DSCORE = 2 };
+
+// X rows: prec (FWD, DPREC) or score (DSCORE).  Y rows: the other matrix.
+template <int MODE>
+__global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ prec, const float* __restrict__ score,
+                                                      const float* __restrict__ log_mask, CeBufs b, int64_t bs, int S,
+                                                      float d_loss, float* __restrict__ dX) {
+    __shared__ __attribute__((aligned(16))) float sY[4][16 * YLD];
+    __shared__ float sRed[4][16][E + 4];
+    const int S1 = S + 1;
+    const int64_t T = bs * S, M = bs * S1;
+    const float* X = MODE == CE_DSCORE ? score : prec;
+    const float* Y = MODE == CE_DSCORE ? prec : score;
+    const int64_t NX = MODE == CE_DSCORE ? M : T, NY = MODE == CE_DSCORE ? T : M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t x0 = (int64_t)blockIdx.x * 16;
+    const int64_t x = x0 + j;
+    const bool xok = x < NX;
+    const int64_t xc = xok ? x : NX - 1;
+
+    // X fragments (B operand): e(ks, kq) = 16*kq + ks  -> 16 consecutive floats per lane
+    float xb[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const f4 t = *(const f4*)(X + xc * E + 16 * g + 4 * v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[4 * v + e] = t[e];
+    }
+
+    // per-X-row constants
+    int64_t row_seq = 0, row_label = 0;
+    float row_lse = 0.f, row_scale = 0.f;
+    bool row_valid = false;
+    int col_id = 0, col_pad = 0;
+    float col_debias = 0.f;
+    if (MODE != CE_DSCORE) {
+        row_seq = xc / S;
+        row_label = row_seq * S1 + (xc - row_seq * S) + 1;
+        row_valid = xok && log_mask[xc] != 0.f;
+        if (MODE == CE_DPREC) {
+            row_lse = b.lse[xc];
+            row_scale = row_valid ? d_loss / b.nvalid[0] : 0.f;
+        }
+    } else {
+        col_id = b.ids32[xc];
+        col_pad = b.colpad[xc];
+        col_debias = b.debias[xc];
+    }
+
+    float run_m = -INFINITY, run_l = 0.f, zlab = 0.f;
+    f4 dacc[4];
+#pragma unroll
+    for (int et = 0; et < 4; ++et) dacc[et] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    float* myY = sY[wave];
+    const int64_t ntiles = (NY + 15) / 16;
+    for (int64_t yt = wave; yt < ntiles; yt += 4) {
+        const int64_t y0 = yt * 16;
+        // stage the Y tile: 16 rows x 64 floats, lane -> row lane>>2, 16-float chunk lane&3
+        {
+            const int r = lane >> 2, ch = lane & 3;
+            const int64_t yr = y0 + r;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                f4 t = {0.f, 0.f, 0.f, 0.f};
+                if (yr < NY) t = *(const f4*)(Y + yr * E + ch * 16 + v * 4);
+                *(f4*)(myY + r * YLD + ch * 16 + v * 4) = t;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Z^T tile: A = Y rows (i = lane&15), B = X rows
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f4 ya = *(const f4*)(myY + j * YLD + 16 * g + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
+        }
+        // lane holds z(x, y = y0 + 4g + r)
+        float dz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t y = y0 + 4 * g + r;
+            const bool yok = y < NY;
+            const int64_t yc = yok ? y : NY - 1;
+            int64_t row, col, seq, label;
+            int idc, pad;
+            float deb;
+            if (MODE != CE_DSCORE) {
+                row = xc; col = yc; seq = row_seq; label = row_label;
+                idc = b.ids32[col]; pad = b.colpad[col]; deb = b.debias[col];
+            } else {
+                row = yc; col = xc; seq = row / S; label = seq * S1 + (row - seq * S) + 1;
+                idc = col_id; pad = col_pad; deb = col_debias;
+            }
+            float val = z[r] - deb;
+            if (pad) val = MASKV;
+            else if (col != label && id_in_seq(b.ids32, seq, S1, idc)) val = MASKV;
+            if (MODE == CE_FWD) {
+                if (yok) {
+                    if (val > run_m) {
+                        run_l = run_l * expf(run_m - val) + 1.f;
+                        run_m = val;
+                    } else {
+                        run_l += expf(val - run_m);
+                    }
+                    if (col == label) zlab = val;
+                }
+            } else {
+                float lse, scale;
+                if (MODE == CE_DPREC) {
+                    lse = row_lse; scale = row_scale;
+                } else {
+                    lse = b.lse[row];
+                    scale = log_mask[row] != 0.f ? d_loss / b.nvalid[0] : 0.f;
+                }
+                const float p = expf(val - lse);
+                dz[r] = (yok && xok) ? (p - (col == label ? 1.f : 0.f)) * scale : 0.f;
+            }
+        }
+        if (MODE != CE_FWD) {
+            // dX^T[e][x] += sum_y Y[y][e] dZ(x,y):  A = Y^T (i = e within tile et, k = y0 + 4kq + r), B = dz[r]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int et = 0; et < 4; ++et) {
+                    const float ya = myY[(4 * g + r) * YLD + 16 * et + j];
+                    dacc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya, dz[r], dacc[et], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (MODE == CE_FWD) {
+        // combine (m, l) and the label logit across the 4 lane groups and the 4 waves
+        auto comb = [](float& m, float& l, float m2, float l2) {
+            const float mn = fmaxf(m, m2);
+            const float a = m == -INFINITY ? 0.f : l * expf(m - mn);
+            const float c = m2 == -INFINITY ? 0.f : l2 * expf(m2 - mn);
+            m = mn;
+            l = a + c;
+        };
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float m2 = __shfl_xor(run_m, o, 64), l2 = __shfl_xor(run_l, o, 64);
+            comb(run_m, run_l, m2, l2);
+            zlab += __shfl_xor(zlab, o, 64);
+        }
+        if (g == 0) {
+            sRed[wave][j][0] = run_m;
+            sRed[wave][j][1] = run_l;
+            sRed[wave][j][2] = zlab;
+        }
+        __syncthreads();
+        if (wave == 0 && g == 0 && xok) {
+            float m = sRed[0][j][0], l = sRed[0][j][1], zl = sRed[0][j][2];
+            for (int w = 1; w < 4; ++w) {
+                comb(m, l, sRed[w][j][0], sRed[w][j][1]);
+                zl += sRed[w][j][2];
+            }
+            const float lse = m + logf(l);
+            b.lse[x] = lse;
+            b.rowloss[x] = row_valid ? lse - zl : 0.f;
+        }
+    } else {
+        // lane (j, g) holds dX[x0+j][16et + 4g + r]; sum over the 4 waves
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sRed[wave][j][16 * et + 4 * g + r] = dacc[et][r];
+        __syncthreads();
+        for (int i = tid; i < 16 * E; i += 256) {
+            const int rj = i / E, e = i - rj * E;
+            if (x0 + rj < NX) dX[(x0 + rj) * E + e] = sRed[0][rj][e] + sRed[1][rj][e] + sRed[2][rj][e] + sRed[3][rj][e];
+        }
+    }
+}
+
+int check(int64_t bs, int S, int Ein) {
+    IISAN_CHECK_SHAPE(bs > 0 && S >= 1 && S <= 63, "inbatch_ce: bs %lld / S %d unsupported", (long long)bs, S);
+    IISAN_CHECK_SHAPE(Ein == E, "inbatch_ce: embedding_dim must be %d (got %d)", E, Ein);
+    return IISAN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
+    WsCarver c(nullptr, 0);
+    CeBufs b;
+    carve(c, b, bs, S);
+    return c.off;
+}
+
+extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
+                                    const float* pop_prob, int64_t bs, int32_t S, int32_t Ein, float* loss, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_TRY(check(bs, S, Ein));
+    WsCarver c(ws, ws_bytes);
+    CeBufs b;
+    carve(c, b, bs, S);
+    if (c.overflow || !ws) {
+        iisan_set_error("inbatch_ce_fwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int64_t T = bs * S, M = bs * (S + 1);
+    hipLaunchKernelGGL(ce_prep_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, s, ids, log_mask, pop_prob, b, bs, S);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(ce_pass_kernel<CE_FWD>, dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S, 0.f,
+                       (float*)nullptr);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, b.rowloss, T, b.nvalid, loss);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
+                                    const float* pop_prob, int64_t bs, int32_t S, int32_t Ein, float d_loss, float* d_score,
+                                    float* d_prec, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_TRY(check(bs, S, Ein));
+    WsCarver c(ws, ws_bytes);
+    CeBufs b;
+    carve(c, b, bs, S);       // ids32/debias/colpad/lse/nvalid were filled by the forward call on the same workspace
+    if (c.overflow || !ws) {
+        iisan_set_error("inbatch_ce_bwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int64_t T = bs * S, M = bs * (S + 1);
+    hipLaunchKernelGGL(ce_pass_kernel<CE_DPREC>, dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+                       d_loss, d_prec);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(ce_pass_kernel<CE_DSCORE>, dim3((unsigned)ceil_div(M, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+                       d_loss, d_score);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}

@@ -1,0 +1,269 @@
+// fp32 GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector
+// rate) for everything TRAINABLE on the hot path: SANB down/up projections, fc_* heads, com_dense, SASRec
+// projections/FFN and all their backward products (dX = dY·W, dW += dY^T·X).  These are <0.1 % of the step's
+// FLOPs but carry the parity budget, hence fp32 end to end.
+//
+//   C[M,N] (=|+=) epilogue( op(A)[M,K] · op(B)[K,N] )
+//   op(A): A stored [M,K] (default) or [K,M] (G32_TA)       op(B): B stored [N,K] (default, torch Linear.weight)
+//                                                                     or [K,N] (G32_TB)
+// 64x64x16 tile per 256-thread workgroup (4 waves, 32x32 each = 2x2 MFMA fragments); operands staged through LDS
+// (17-float rows) with 16-byte global loads; up to 4 independent problems per launch (blockIdx.z) so the cv / text /
+// mm towers of the side network go out together; split-K (blockIdx.y) with fp32 atomics for the weight-gradient
+// products whose M,N are tiny and K = number of item slots.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16, LD = 17;
+
+struct Gemm32Batch {
+    Gemm32Prob p[4];
+};
+
+// stage a 64 x 16 operand tile into LDS as S[row][k].  `trans`: source stored [K, rows] (row index contiguous).
+__device__ __forceinline__ void stage_tile(float (*S)[LD], const float* __restrict__ src, int ld, bool trans,
+                                           int64_t row0, int64_t rows, int64_t k0, int64_t kend, int tid) {
+    if (!trans) {
+        const int r = tid >> 2, kc = (tid & 3) * 4;
+        const int64_t row = row0 + r, k = k0 + kc;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows) {
+            const float* p = src + row * ld + k;
+            if (k + 3 < kend && (((uintptr_t)p) & 15) == 0) {
+                v = *(const f4*)p;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < kend) v[e] = p[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[r][kc + e] = v[e];
+    } else {
+        const int kk = tid >> 4, rc = (tid & 15) * 4;
+        const int64_t k = k0 + kk, row = row0 + rc;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+            const float* p = src + k * ld + row;
+            if (row + 3 < rows && (((uintptr_t)p) & 15) == 0) {
+                v = *(const f4*)p;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (row + e < rows) v[e] = p[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[rc + e][kk] = v[e];
+    }
+}
+
+// structural flags (operand layouts, atomic accumulate) are compile time; epilogue flags are run time
+template <int FLAGS>
+__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
+    __shared__ float As[TM][LD];
+    __shared__ float Bs[TN][LD];
+    const Gemm32Prob& p = batch.p[blockIdx.z];
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int64_t tiles_m = (p.M + TM - 1) / TM;
+    if ((int64_t)blockIdx.x >= tiles_m * tiles_n) return;
+    const int64_t tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const int64_t m0 = tile_m * TM;
+    const int n0 = tile_n * TN;
+
+    // K range of this split
+    const int64_t ktiles = (p.K + TK - 1) / TK;
+    const int64_t per = (ktiles + gridDim.y - 1) / gridDim.y;
+    const int64_t kbeg = (int64_t)blockIdx.y * per * TK;
+    int64_t kend = kbeg + per * TK;
+    if (kend > p.K) kend = p.K;
+    if (kbeg >= kend && blockIdx.y > 0) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 15, fk = lane >> 4;
+
+    f4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
+        stage_tile(As, p.A, p.lda, (FLAGS & G32_TA) != 0, m0, p.M, k0, kend, tid);
+        stage_tile(Bs, p.B, p.ldb, (FLAGS & G32_TB) != 0, n0, p.N, k0, kend, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = As[wm * 32 + f * 16 + fi][ks * 4 + fk];
+                b[f] = Bs[wn * 32 + f * 16 + fi][ks * 4 + fk];
+            }
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const bool first_split = blockIdx.y == 0;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            const int n = n0 + wn * 32 + nf * 16 + fi;
+            if (n >= p.N) continue;
+            const float bias = (p.bias && first_split) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm * 32 + mf * 16 + fk * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[mf][nf][r] + bias;
+                if (epi & G32_PREACT) ((float*)p.act_src)[m * p.ldc + n] = v;
+                if (epi & G32_RELU) v = fmaxf(v, 0.f);
+                if (epi & G32_GELU) v = gelu_erf(v);
+                if (epi & G32_MUL_RELU_MASK) v = p.act_src[m * p.ldc + n] > 0.f ? v : 0.f;
+                if (epi & G32_MUL_GELU_GRAD) v *= gelu_erf_grad(p.act_src[m * p.ldc + n]);
+                if (p.resid && first_split) v += p.resid[m * p.ldr + n];
+                if constexpr ((FLAGS & G32_ACCUM) != 0)
+                    atomicAdd(p.C + m * p.ldc + n, v);
+                else
+                    p.C[m * p.ldc + n] = v;
+            }
+        }
+}
+
+// column sums: out[n] += sum_m X[m][n]  (bias gradients); up to 4 problems per launch
+struct ColsumBatch {
+    const float* X[4];
+    float* out[4];
+    int64_t M[4];
+    int32_t N[4], ld[4];
+};
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int z = blockIdx.z;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > b.M[z]) r1 = b.M[z];
+    float s = 0.f;
+    if (n < b.N[z])
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += b.X[z][r * b.ld[z] + n];
+    part[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
+template <int FLAGS>
+int launch_flags(const Gemm32Batch& b, dim3 grid, int epi, hipStream_t s) {
+    hipLaunchKernelGGL(gemm32_kernel<FLAGS>, grid, dim3(256), 0, s, b, epi);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+}  // namespace
+
+int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
+    IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
+    Gemm32Batch b{};
+    int64_t max_tiles = 0, min_k = INT64_MAX;
+    for (int i = 0; i < nprob; ++i) {
+        b.p[i] = probs[i];
+        IISAN_CHECK_SHAPE(probs[i].M > 0 && probs[i].N > 0 && probs[i].K > 0, "gemm32: empty problem %d", i);
+        const int64_t t = ceil_div(probs[i].M, TM) * ceil_div(probs[i].N, TN);
+        if (t > max_tiles) max_tiles = t;
+        if (probs[i].K < min_k) min_k = probs[i].K;
+    }
+    IISAN_CHECK_SHAPE(max_tiles < (1ll << 31), "gemm32: grid too large");
+    int splitk = 1;
+    if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
+        const int64_t want = ceil_div(1024, max_tiles * nprob);
+        const int64_t maxs = ceil_div(min_k, 4 * TK);
+        splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+        if (splitk < 1) splitk = 1;
+    }
+    dim3 grid((unsigned)max_tiles, (unsigned)splitk, (unsigned)nprob);
+    const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
+    const int epi = flags & ~structural;
+    switch (structural) {
+#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, epi, s)
+        G32_CASE(0);
+        G32_CASE(G32_TA);
+        G32_CASE(G32_TB);
+        G32_CASE(G32_TA | G32_TB);
+        G32_CASE(G32_ACCUM);
+        G32_CASE(G32_TA | G32_ACCUM);
+        G32_CASE(G32_TB | G32_ACCUM);
+        G32_CASE(G32_TA | G32_TB | G32_ACCUM);
+#undef G32_CASE
+        default: iisan_set_error("gemm32: bad flags 0x%x", flags); return IISAN_EBADSHAPE;
+    }
+}
+
+int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
+                  int nprob, hipStream_t s) {
+    IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "colsum: 1..4 problems per launch");
+    ColsumBatch b{};
+    int64_t maxM = 0;
+    int maxN = 0;
+    for (int i = 0; i < nprob; ++i) {
+        b.X[i] = X[i]; b.out[i] = out[i]; b.M[i] = M[i]; b.N[i] = N[i]; b.ld[i] = ld[i];
+        if (M[i] > maxM) maxM = M[i];
+        if (N[i] > maxN) maxN = N[i];
+    }
+    const int rows_per_block = 256;
+    dim3 grid((unsigned)ceil_div(maxN, 64), (unsigned)ceil_div(maxM, rows_per_block), (unsigned)nprob);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, b, rows_per_block);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+extern "C" int iisan_gemm32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
+                            int32_t ta, int32_t tb, int32_t relu, int32_t accumulate, void* stream) {
+    Gemm32Prob p{};
+    p.A = A; p.B = B; p.bias = bias; p.resid = nullptr; p.act_src = nullptr; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = ta ? (int32_t)M : (int32_t)K;
+    p.ldb = tb ? N : (int32_t)K;
+    p.ldc = N; p.ldr = N;
+    int flags = (ta ? G32_TA : 0) | (tb ? G32_TB : 0) | (relu ? G32_RELU : 0) | (accumulate ? G32_ACCUM : 0);
+    return launch_gemm32(&p, 1, flags, (hipStream_t)stream);
+}
+
+extern "C" int iisan_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int32_t K, int32_t N,
+                                void* stream) {
+    Gemm32Prob p{};
+    p.A = x; p.B = w; p.bias = b; p.C = y; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ldr = N;
+    return launch_gemm32(&p, 1, 0, (hipStream_t)stream);
+}
+
+// dx = dy · W ; dW += dy^T · x ; db += colsum(dy)   (dx / dw / db may be NULL to skip)
+extern "C" int iisan_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                int64_t M, int32_t K, int32_t N, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        Gemm32Prob p{};
+        p.A = dy; p.B = w; p.C = dx; p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = K; p.ldc = K; p.ldr = K;
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
+    }
+    if (dw) {
+        Gemm32Prob p{};
+        p.A = dy; p.B = x; p.C = dw; p.M = N; p.N = K; p.K = M; p.lda = N; p.ldb = K; p.ldc = K; p.ldr = K;
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));
+    }
+    if (db) {
+        const float* X[1] = {dy};
+        float* O[1] = {db};
+        int64_t Ms[1] = {M};
+        int32_t Ns[1] = {N}, lds[1] = {N};
+        IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, 1, s));
+    }
+    return IISAN_OK;
+}

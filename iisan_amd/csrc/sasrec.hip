@@ -1,0 +1,380 @@
+// SASRec user encoder: forward + backward executors and their small kernels.
+// Replaces User_Encoder.forward (Code_Uncached/model/encoders.py:60-65) -> TransformerEncoder / TransformerBlock /
+// MultiHeadedAttention / SelfAttention / PositionwiseFeedForward (Code_*/model/modules.py:6-96), and the backward
+// autograd derives from them.  fp32 throughout (d_model 64, 2 heads, 10 positions: ~2 MFLOP per sequence).
+//
+//   X0 = LN(in + pos)                                              (eps 1e-6)
+//   per block:  Q,K,V = X·Wq^T, X·Wk^T, X·Wv^T (no bias) ; P = softmax(QK^T/sqrt(dh) + mask) ; C = P·V
+//               X1 = LN(X + C·Wfc^T) ; X2 = LN(X1 + W2·relu(W1·X1 + b1) + b2)
+//   mask[q,k] = 0 if (k <= q and log_mask[k] != 0) else -1e9      (encoders.py:60-64)
+//
+// Projections/FFN run as fp32-MFMA GEMMs over all B*S rows (gemm32.hip); LayerNorm fwd/bwd are one-wave-per-row
+// shuffle kernels; the 10x10 attention is a thread-per-query-row kernel.  Dropout (reference drop_rate 0.1 in
+// training) is not implemented yet: cfg.dropout must be 0 (eval semantics), enforced loudly.
+#include "common.h"
+
+int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
+                  int nprob, hipStream_t s);
+
+namespace {
+
+constexpr int MAXE = 256;   // d_model up to 256 (multiple of 64)
+
+// y = LN(a + b) * g + beta ; optionally stores the pre-norm sum z = a + b (needed by backward).
+// b_stride_rows: b is indexed by (row % b_rows) (position embedding) when b_rows > 0, else by row.
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t b_rows, const float* __restrict__ g,
+                                                         const float* __restrict__ beta, float eps, float* __restrict__ zsum,
+                                                         float* __restrict__ y, int64_t rows, int E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int per = E / 64;
+    float v[MAXE / 64];
+    float s = 0.f;
+    const int64_t brow = b_rows > 0 ? row % b_rows : row;
+    for (int i = 0; i < per; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = a[row * E + c] + (b ? b[brow * E + c] : 0.f);
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int i = 0; i < per; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+    for (int i = 0; i < per; ++i) {
+        const int c = i * 64 + lane;
+        if (zsum) zsum[row * E + c] = v[i];
+        y[row * E + c] = (v[i] - mean) * rstd * g[c] + beta[c];
+    }
+}
+
+// LayerNorm backward on rows z (pre-norm input): dz = rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat));
+// dgamma += sum dy*xhat ; dbeta += sum dy.  64 rows per block, block-level reduction, then atomics.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                     const float* __restrict__ g, float eps, float* __restrict__ dz,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int E) {
+    __shared__ float red[2][4][MAXE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = E / 64;
+    float dg[MAXE / 64], db[MAXE / 64];
+    for (int i = 0; i < per; ++i) dg[i] = db[i] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        float v[MAXE / 64], d[MAXE / 64];
+        float s = 0.f;
+        for (int i = 0; i < per; ++i) {
+            v[i] = z[row * E + i * 64 + lane];
+            d[i] = dy[row * E + i * 64 + lane];
+            s += v[i];
+        }
+        const float mean = wave_sum(s) / (float)E;
+        float q = 0.f;
+        for (int i = 0; i < per; ++i) {
+            v[i] -= mean;
+            q += v[i] * v[i];
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < per; ++i) {
+            const int c = i * 64 + lane;
+            v[i] *= rstd;                    // xhat
+            dg[i] += d[i] * v[i];
+            db[i] += d[i];
+            d[i] *= g[c];                    // dy * gamma
+            s1 += d[i];
+            s2 += d[i] * v[i];
+        }
+        s1 = wave_sum(s1) / (float)E;
+        s2 = wave_sum(s2) / (float)E;
+        for (int i = 0; i < per; ++i) dz[row * E + i * 64 + lane] = rstd * (d[i] - s1 - v[i] * s2);
+    }
+    for (int i = 0; i < per; ++i) {
+        red[0][wave][i * 64 + lane] = dg[i];
+        red[1][wave][i * 64 + lane] = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// attention forward: one thread per (b, h, q).  Q/K/V: [B*S, E] (head h = columns h*dh..); P: [B,H,S,S]; C: [B*S,E]
+__global__ void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                    const float* __restrict__ log_mask, float* __restrict__ P, float* __restrict__ C,
+                                    int64_t B, int S, int H, int dh) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * S) return;
+    const int q = (int)(i % S);
+    const int h = (int)((i / S) % H);
+    const int64_t b = i / ((int64_t)S * H);
+    const int E = H * dh;
+    const float temp = sqrtf((float)dh);
+    const float* qr = Q + (b * S + q) * E + h * dh;
+    float sc[32];
+    float mx = -INFINITY;
+    for (int k = 0; k < S; ++k) {
+        const float* kr = K + (b * S + k) * E + h * dh;
+        float d = 0.f;
+        for (int e = 0; e < dh; ++e) d += qr[e] * kr[e];
+        const float m = (k <= q && log_mask[b * S + k] != 0.f) ? 0.f : -1e9f;
+        sc[k] = d / temp + m;
+        mx = fmaxf(mx, sc[k]);
+    }
+    float sum = 0.f;
+    for (int k = 0; k < S; ++k) {
+        sc[k] = expf(sc[k] - mx);
+        sum += sc[k];
+    }
+    float* pr = P + ((b * H + h) * S + q) * S;
+    for (int k = 0; k < S; ++k) {
+        sc[k] /= sum;
+        pr[k] = sc[k];
+    }
+    float* cr = C + (b * S + q) * E + h * dh;
+    for (int e = 0; e < dh; ++e) {
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) acc += sc[k] * V[(b * S + k) * E + h * dh + e];
+        cr[e] = acc;
+    }
+}
+
+// attention backward: one block (64 threads) per sequence b; thread (h, q) first builds dS rows into LDS, then
+// thread (h, k) gathers dK, dV over queries.
+__global__ __launch_bounds__(64) void sas_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                          const float* __restrict__ V, const float* __restrict__ P,
+                                                          const float* __restrict__ dC, float* __restrict__ dQ,
+                                                          float* __restrict__ dK, float* __restrict__ dV, int S, int H, int dh) {
+    __shared__ float dS[64 * 32];     // [(h*S + q)][k], S <= 32, H*S <= 64
+    const int64_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    const int E = H * dh;
+    const float temp = sqrtf((float)dh);
+    const bool act = t < H * S;
+    const int h = act ? t / S : 0, q = act ? t % S : 0;
+    if (act) {
+        const float* pr = P + ((b * H + h) * S + q) * S;
+        const float* dc = dC + (b * S + q) * E + h * dh;
+        float dp[32];
+        float dot = 0.f;
+        for (int k = 0; k < S; ++k) {
+            const float* vr = V + (b * S + k) * E + h * dh;
+            float d = 0.f;
+            for (int e = 0; e < dh; ++e) d += dc[e] * vr[e];
+            dp[k] = d;
+            dot += pr[k] * d;
+        }
+        for (int k = 0; k < S; ++k) dS[t * 32 + k] = pr[k] * (dp[k] - dot) / temp;
+        float* dq = dQ + (b * S + q) * E + h * dh;
+        for (int e = 0; e < dh; ++e) {
+            float acc = 0.f;
+            for (int k = 0; k < S; ++k) acc += dS[t * 32 + k] * K[(b * S + k) * E + h * dh + e];
+            dq[e] = acc;
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const int k = q;               // this thread now owns key/value row k of head h
+        float* dk = dK + (b * S + k) * E + h * dh;
+        float* dv = dV + (b * S + k) * E + h * dh;
+        for (int e = 0; e < dh; ++e) {
+            float ak = 0.f, av = 0.f;
+            for (int qq = 0; qq < S; ++qq) {
+                ak += dS[(h * S + qq) * 32 + k] * Q[(b * S + qq) * E + h * dh + e];
+                av += P[((b * H + h) * S + qq) * S + k] * dC[(b * S + qq) * E + h * dh + e];
+            }
+            dk[e] = ak;
+            dv[e] = av;
+        }
+    }
+}
+
+struct BlockBufs {
+    float *Q, *K, *V, *P, *C, *Zattn, *X1, *Hf, *Zffn, *X2;
+};
+struct SasBufs {
+    float* Z0;              // in + pos
+    float* X0;              // LN(Z0)
+    BlockBufs blk[8];
+    float *dA, *dB, *dQ, *dK, *dV, *dH;     // backward scratch
+};
+
+void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
+    const size_t T = (size_t)B * cfg->seq, E = cfg->emb;
+    b.Z0 = c.take<float>(T * E);
+    b.X0 = c.take<float>(T * E);
+    for (int l = 0; l < cfg->blocks; ++l) {
+        BlockBufs& k = b.blk[l];
+        k.Q = c.take<float>(T * E); k.K = c.take<float>(T * E); k.V = c.take<float>(T * E);
+        k.P = c.take<float>((size_t)B * cfg->heads * cfg->seq * cfg->seq);
+        k.C = c.take<float>(T * E); k.Zattn = c.take<float>(T * E); k.X1 = c.take<float>(T * E);
+        k.Hf = c.take<float>(T * 4 * E); k.Zffn = c.take<float>(T * E); k.X2 = c.take<float>(T * E);
+    }
+    b.dA = c.take<float>(T * E); b.dB = c.take<float>(T * E);
+    b.dQ = c.take<float>(T * E); b.dK = c.take<float>(T * E); b.dV = c.take<float>(T * E);
+    b.dH = c.take<float>(T * 4 * E);
+}
+
+int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {
+    IISAN_CHECK_SHAPE(B > 0, "sasrec: empty batch");
+    IISAN_CHECK_SHAPE(cfg->emb % 64 == 0 && cfg->emb <= MAXE, "sasrec: d_model %d must be a multiple of 64 and <= %d", cfg->emb, MAXE);
+    IISAN_CHECK_SHAPE(cfg->heads > 0 && cfg->emb % cfg->heads == 0, "sasrec: heads %d does not divide d_model %d", cfg->heads, cfg->emb);
+    IISAN_CHECK_SHAPE(cfg->seq >= 1 && cfg->seq <= 32 && cfg->seq * cfg->heads <= 64, "sasrec: seq %d x heads %d unsupported", cfg->seq, cfg->heads);
+    IISAN_CHECK_SHAPE(cfg->blocks >= 1 && cfg->blocks <= 8, "sasrec: %d blocks unsupported", cfg->blocks);
+    IISAN_CHECK_SHAPE(cfg->dropout == 0.f, "sasrec: dropout %.3f requested but only eval semantics (dropout 0) are "
+                      "implemented in this round", cfg->dropout);
+    return IISAN_OK;
+}
+
+Gemm32Prob prob(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int64_t M, int N,
+                int64_t K, const float* resid = nullptr, const float* act_src = nullptr) {
+    Gemm32Prob p{};
+    p.A = A; p.B = B; p.bias = bias; p.resid = resid; p.act_src = act_src; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldc;
+    return p;
+}
+
+// parameter table: 0 pos, 1 ln.w, 2 ln.b, then 12 per block:
+// +0 wQ +1 wK +2 wV +3 fc +4 attn_ln.w +5 attn_ln.b +6 w1.w +7 w1.b +8 w2.w +9 w2.b +10 ffn_ln.w +11 ffn_ln.b
+inline int pb(int l, int i) { return 3 + 12 * l + i; }
+
+}  // namespace
+
+extern "C" size_t iisan_sasrec_ws_bytes(const iisan_sasrec_cfg* cfg, int64_t B) {
+    WsCarver c(nullptr, 0);
+    SasBufs b;
+    carve(c, b, cfg, B);
+    return c.off;
+}
+
+extern "C" int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B,
+                                const void* const* params, float* y, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_TRY(check_cfg(cfg, B));
+    WsCarver c(ws, ws_bytes);
+    SasBufs b;
+    carve(c, b, cfg, B);
+    if (c.overflow || !ws) {
+        iisan_set_error("sasrec_fwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int S = cfg->seq, E = cfg->emb, H = cfg->heads, dh = E / H;
+    const int64_t T = B * S;
+    auto W = [&](int i) { return (const float*)params[i]; };
+    const dim3 ln_grid((unsigned)ceil_div(T, 4)), blk(256);
+    hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, x, W(0), (int64_t)S, W(1), W(2), 1e-6f, b.Z0, b.X0, T, E);
+    IISAN_LAUNCH_OK();
+    const float* xin = b.X0;
+    for (int l = 0; l < cfg->blocks; ++l) {
+        BlockBufs& k = b.blk[l];
+        Gemm32Prob pr[3] = {prob(xin, E, W(pb(l, 0)), E, nullptr, k.Q, E, T, E, E), prob(xin, E, W(pb(l, 1)), E, nullptr, k.K, E, T, E, E),
+                            prob(xin, E, W(pb(l, 2)), E, nullptr, k.V, E, T, E, E)};
+        IISAN_TRY(launch_gemm32(pr, 3, 0, s));
+        hipLaunchKernelGGL(sas_attn_fwd_kernel, dim3((unsigned)ceil_div(B * H * S, 128)), dim3(128), 0, s, k.Q, k.K, k.V,
+                           log_mask, k.P, k.C, B, S, H, dh);
+        IISAN_LAUNCH_OK();
+        Gemm32Prob pf = prob(k.C, E, W(pb(l, 3)), E, nullptr, k.Zattn, E, T, E, E, xin);        // x + fc(ctx)
+        IISAN_TRY(launch_gemm32(&pf, 1, 0, s));
+        hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, k.Zattn, (const float*)nullptr, (int64_t)0, W(pb(l, 4)),
+                           W(pb(l, 5)), 1e-6f, (float*)nullptr, k.X1, T, E);
+        IISAN_LAUNCH_OK();
+        Gemm32Prob p1 = prob(k.X1, E, W(pb(l, 6)), E, W(pb(l, 7)), k.Hf, 4 * E, T, 4 * E, E);   // relu(W1 x + b1)
+        IISAN_TRY(launch_gemm32(&p1, 1, G32_RELU, s));
+        Gemm32Prob p2 = prob(k.Hf, 4 * E, W(pb(l, 8)), 4 * E, W(pb(l, 9)), k.Zffn, E, T, E, 4 * E, k.X1);
+        IISAN_TRY(launch_gemm32(&p2, 1, 0, s));
+        float* out = (l == cfg->blocks - 1) ? y : k.X2;
+        hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, k.Zffn, (const float*)nullptr, (int64_t)0, W(pb(l, 10)),
+                           W(pb(l, 11)), 1e-6f, (float*)nullptr, out, T, E);
+        IISAN_LAUNCH_OK();
+        xin = out;
+    }
+    return IISAN_OK;
+}
+
+extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B,
+                                const void* const* params, const float* dy, float* dx, void* const* grads, void* ws,
+                                size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_TRY(check_cfg(cfg, B));
+    WsCarver c(ws, ws_bytes);
+    SasBufs b;
+    carve(c, b, cfg, B);
+    if (c.overflow || !ws) {
+        iisan_set_error("sasrec_bwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
+        return IISAN_EWORKSPACE;
+    }
+    const int S = cfg->seq, E = cfg->emb, H = cfg->heads, dh = E / H;
+    const int64_t T = B * S;
+    auto W = [&](int i) { return (const float*)params[i]; };
+    auto G = [&](int i) { return (float*)grads[i]; };
+    const dim3 lnb_grid((unsigned)ceil_div(T, 64)), blk(256);
+    const float* dcur = dy;        // gradient wrt the current block's output X2
+    for (int l = cfg->blocks - 1; l >= 0; --l) {
+        BlockBufs& k = b.blk[l];
+        const float* xin = l == 0 ? b.X0 : b.blk[l - 1].X2;
+        // X2 = LN(Zffn): dZffn -> dA
+        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zffn, dcur, W(pb(l, 10)), 1e-6f, b.dA, G(pb(l, 10)), G(pb(l, 11)), T, E);
+        IISAN_LAUNCH_OK();
+        // Zffn = X1 + Hf W2^T + b2
+        Gemm32Prob p = prob(b.dA, E, W(pb(l, 8)), 4 * E, nullptr, b.dH, 4 * E, T, 4 * E, E, nullptr, k.Hf);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB | G32_MUL_RELU_MASK, s));                       // dH = (dA·W2) ⊙ [Hf>0]
+        p = prob(b.dA, E, k.Hf, 4 * E, nullptr, G(pb(l, 8)), 4 * E, E, 4 * E, T);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dW2 += dA^T·Hf
+        p = prob(b.dH, 4 * E, k.X1, E, nullptr, G(pb(l, 6)), E, 4 * E, E, T);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dW1 += dH^T·X1
+        {
+            const float* X[2] = {b.dA, b.dH};
+            float* O[2] = {G(pb(l, 9)), G(pb(l, 7))};
+            int64_t Ms[2] = {T, T};
+            int32_t Ns[2] = {E, 4 * E}, lds[2] = {E, 4 * E};
+            IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, 2, s));                                // db2, db1
+        }
+        p = prob(b.dH, 4 * E, W(pb(l, 6)), E, nullptr, b.dB, E, T, E, 4 * E, b.dA);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dX1 = dA + dH·W1
+        // X1 = LN(Zattn): dZattn -> dA
+        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zattn, b.dB, W(pb(l, 4)), 1e-6f, b.dA, G(pb(l, 4)), G(pb(l, 5)), T, E);
+        IISAN_LAUNCH_OK();
+        // Zattn = xin + C Wfc^T
+        p = prob(b.dA, E, W(pb(l, 3)), E, nullptr, b.dB, E, T, E, E);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dC = dA·Wfc
+        p = prob(b.dA, E, k.C, E, nullptr, G(pb(l, 3)), E, E, E, T);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dWfc += dA^T·C
+        hipLaunchKernelGGL(sas_attn_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, k.Q, k.K, k.V, k.P, b.dB, b.dQ, b.dK, b.dV, S, H, dh);
+        IISAN_LAUNCH_OK();
+        {
+            Gemm32Prob pr[3] = {prob(b.dQ, E, xin, E, nullptr, G(pb(l, 0)), E, E, E, T), prob(b.dK, E, xin, E, nullptr, G(pb(l, 1)), E, E, E, T),
+                                prob(b.dV, E, xin, E, nullptr, G(pb(l, 2)), E, E, E, T)};
+            IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));                  // dWq/k/v
+        }
+        // dxin = dA + dQ·Wq + dK·Wk + dV·Wv   (chained through the residual input, in place in dA)
+        p = prob(b.dQ, E, W(pb(l, 0)), E, nullptr, b.dA, E, T, E, E, b.dA);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
+        p = prob(b.dK, E, W(pb(l, 1)), E, nullptr, b.dA, E, T, E, E, b.dA);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
+        float* dst = (l == 0) ? b.dB : (float*)b.blk[l - 1].X2;   // X2 of the block below is dead once consumed: reuse
+        // keep it simple and safe: always write the block-input gradient into dQ (free after the three products)
+        dst = b.dQ;
+        p = prob(b.dV, E, W(pb(l, 2)), E, nullptr, dst, E, T, E, E, b.dA);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
+        // dQ now holds d(xin); move it to dK so the next iteration can reuse dQ/dA/dB freely
+        IISAN_HIP_OK(hipMemcpyAsync(b.dK, dst, (size_t)T * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+        dcur = b.dK;
+    }
+    // X0 = LN(Z0), Z0 = x + pos
+    hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, b.Z0, dcur, W(1), 1e-6f, dx, G(1), G(2), T, E);
+    IISAN_LAUNCH_OK();
+    {
+        const float* X[1] = {dx};
+        float* O[1] = {G(0)};
+        int64_t Ms[1] = {B};
+        int32_t Ns[1] = {S * E}, lds[1] = {S * E};
+        IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, 1, s));                                    // dpos[s,e] = sum_b dx[b,s,e]
+    }
+    return IISAN_OK;
+}

@@ -1,0 +1,147 @@
+"""`ModelMM` and `IISANAdaptedMModel` mirroring `Code_Uncached/model/model.py` (and the Cached wrapper of
+`Code_Cached/model/model.py:257-349`): identical constructors, forward signatures, return conventions and state-dict
+keys; the forward runs on the HIP library (frozen encoders -> CLS taps -> fused side network -> com_dense -> SASRec ->
+fused in-batch CE)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .encoders import MM_Encoder, User_Encoder
+from .modules import AdapterBlock
+
+__all__ = ["ModelMM", "IISANAdaptedMModel", "CachedIISANAdaptedMModel"]
+
+
+class _SideNetBase(nn.Module):
+    """Everything the Uncached and Cached IISAN wrappers share (`model.py:166-205`)."""
+
+    cached = False
+
+    def _build(self, args):
+        embedding_dim = 768
+        if args.remove_first == "TRUE":             # model.py:172-174 (the reference swaps the two list names here)
+            self.side_bert_adapter_num_list = [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
+            self.side_cv_adapter_num_list = [int(i) + 1 for i in args.side_adapter_bert_list.split(",")]
+        else:                                       # model.py:176-177
+            self.side_bert_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
+            self.side_cv_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
+        if "intra" not in args.modality or "inter" not in args.modality:
+            raise NotImplementedError(f"modality {args.modality!r}: only the IISAN default 'intra_inter' is built")
+        if self.side_bert_adapter_num_list != self.side_cv_adapter_num_list:
+            raise NotImplementedError("different tap lists per tower are the Versa variant (Code_Cached_Asym)")
+        n = len(self.side_cv_adapter_num_list)
+        self.cv_adapter_list = nn.ModuleList([AdapterBlock(args, embedding_dim, args.cv_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
+        self.bert_adapter_list = nn.ModuleList([AdapterBlock(args, args.word_embedding_dim, args.bert_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
+        self.mm_adapter_list = nn.ModuleList([AdapterBlock(args, args.word_embedding_dim, args.bert_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
+        self.fc_bert = nn.Linear(embedding_dim, embedding_dim)
+        self.fc_cv = nn.Linear(embedding_dim, embedding_dim)
+        self.fc_mm = nn.Linear(args.word_embedding_dim, args.word_embedding_dim)
+        self.fc_mm_down = nn.Linear(args.word_embedding_dim, args.embedding_dim)
+        self.gated = args.fusion_method == "gated"
+        if self.gated:                              # model.py:190-205
+            self.side_gate_params_text = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
+            self.side_gate_params_cv = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
+            self.side_gate_params_mm = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
+        self.args = args
+        self.n_side = n
+        self.remove_first = args.remove_first == "TRUE"
+        self._order = ops.side_param_order(n, cached=self.cached)
+
+    def _abi_params(self, device):
+        sd = dict(self.named_parameters())
+        out = []
+        for k in self._order:
+            if k in sd:
+                out.append(sd[k])
+            else:                                    # gates do not exist when fusion_method != "gated"
+                assert "side_gate" in k, k
+                out.append(torch.zeros(1, device=device))
+        return out
+
+    def _side(self, taps_cv, taps_text, tap_index, first_index):
+        cfg = ops.make_side_cfg(self.n_side, taps_cv.shape[-1], self.cv_adapter_list[0].fc_down.out_features,
+                                self.fc_mm_down.out_features, self.gated, self.cv_adapter_list[0].gelu, self.remove_first,
+                                taps_cv.shape[1], taps_text.shape[1], tap_index, first_index)
+        item3 = ops.SideNetFn.apply(cfg, taps_cv, taps_text, *self._abi_params(taps_cv.device))
+        E = cfg.emb
+        return item3, (item3[:, :E], [item3[:, E:2 * E], item3[:, 2 * E:]])
+
+
+class IISANAdaptedMModel(_SideNetBase):
+    """Uncached wrapper (`Code_Uncached/model/model.py:166-271`): owns the two frozen encoders."""
+
+    def __init__(self, mm_model, args):
+        super().__init__()
+        self.cv_encoder = mm_model.cv_encoder
+        self.bert_encoder = mm_model.bert_encoder
+        self._build(args)
+
+    def forward_item3(self, sample_items_images, sample_items_text):
+        layers = self.side_cv_adapter_num_list
+        need = ([0] if self.remove_first else []) + list(layers)        # model.py:215-218 seeds states with tap 0
+        need = sorted(set(need))
+        taps_cv = self.cv_encoder.forward_taps(sample_items_images, need)
+        taps_text = self.bert_encoder.forward_taps(sample_items_text, need)
+        return self._side(taps_cv, taps_text, [need.index(l) for l in layers], need.index(0) if self.remove_first else 0)
+
+    def forward(self, sample_items_images, sample_items_text):
+        return self.forward_item3(sample_items_images, sample_items_text)[1]
+
+
+class CachedIISANAdaptedMModel(_SideNetBase):
+    """Cached wrapper (`Code_Cached/model/model.py:257-349`): inputs are the precomputed CLS taps
+    `[bs, S+1, L+1, 768]` (train) or `[B, L+1, 768]` (eval); only the two 768->64 heads of the encoders are kept."""
+
+    cached = True
+
+    def __init__(self, mm_model, args):
+        super().__init__()
+        self.cv_pre_fc = mm_model.cv_encoder.image_net.classifier
+        self.bert_pre_fc = mm_model.bert_encoder.text_encoders.title.fc
+        self._build(args)
+
+    def forward_item3(self, sample_items_images, sample_items_text):
+        tc = sample_items_images.reshape(-1, sample_items_images.shape[-2], sample_items_images.shape[-1])
+        tt = sample_items_text.reshape(-1, sample_items_text.shape[-2], sample_items_text.shape[-1])
+        return self._side(tc.contiguous(), tt.contiguous(), list(self.side_cv_adapter_num_list), 0)
+
+    def forward(self, sample_items_images, sample_items_text):
+        return self.forward_item3(sample_items_images, sample_items_text)[1]
+
+
+class ModelMM(nn.Module):                          # model.py:14-105
+    def __init__(self, args, item_num, use_modal, image_net, bert_model, pop_prob_list):
+        super().__init__()
+        self.args = args
+        self.use_modal = use_modal
+        self.max_seq_len = args.max_seq_len
+        self.l2_weight = args.l2_weight / 2
+        self.pop_prob_list = torch.as_tensor(pop_prob_list, dtype=torch.float32)
+        self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
+                                         num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
+                                         n_layers=args.transformer_block)
+        if not use_modal:
+            raise NotImplementedError("use_modal=False (ID embeddings) is not the IISAN hot path")
+        self.mm_encoder = MM_Encoder(args, image_net, bert_model)
+        if "intra_inter" not in args.modality:
+            raise NotImplementedError(f"modality {args.modality!r}: only 'intra_inter' is built")
+        self.com_dense = nn.Linear(args.embedding_dim * 3, args.embedding_dim)     # model.py:36-37
+        self.criterion = nn.CrossEntropyLoss()
+
+    def score_embs(self, sample_items_images, sample_items_text):
+        enc = self.mm_encoder
+        if hasattr(enc, "forward_item3"):
+            item3, _ = enc.forward_item3(sample_items_images, sample_items_text)
+        else:
+            raise NotImplementedError("mm_encoder must be wrapped by IISANAdaptedMModel (run.py:214-216)")
+        return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias)             # model.py:67-69
+
+    def forward(self, sample_items_id, sample_items_images, sample_items_text, log_mask, local_rank=None):
+        if self.pop_prob_list.device != log_mask.device:
+            self.pop_prob_list = self.pop_prob_list.to(log_mask.device)                         # model.py:63
+        score_embs = self.score_embs(sample_items_images, sample_items_text)
+        E = self.args.embedding_dim
+        input_embs = score_embs.view(-1, self.max_seq_len + 1, E)
+        prec_vec = self.user_encoder(input_embs[:, :-1, :].contiguous(), log_mask, local_rank)  # model.py:76-77
+        return ops.InbatchCeFn.apply(sample_items_id.view(-1), score_embs, prec_vec.reshape(-1, E), log_mask,
+                                     self.pop_prob_list)                                        # model.py:81-104

@@ -1,0 +1,165 @@
+"""GPU parity of the trainable half of the hot path (side network, com_dense, SASRec, fused in-batch CE, Adam,
+eval ranks) — HIP path through the product modules vs the golden vectors of the real reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_io as gio  # noqa: E402
+import helpers  # noqa: E402
+from iisan_amd import _lib, ops, trainer  # noqa: E402
+from oracle import iisan_oracle as O  # noqa: E402
+
+
+def _close(a, b, rtol, atol, what):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{what}: max|err| {err:.3e} vs scale {ref:.3e}"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("case", [(70, 64, 48, 0, 0), (130, 768, 64, 0, 1), (64, 64, 1408, 1, 1), (33, 192, 64, 0, 0),
+                                  (1000, 257, 100, 1, 0), (5, 3, 7, 0, 1)])
+def test_gemm32_vs_torch(lib, case):
+    M, N, K, ta, tb = case
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((K, N) if tb else (N, K), generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    ref = (A.t() if ta else A).double() @ (B if tb else B.t()).double()
+    Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+    C = torch.empty(M, N, device="cuda")
+    if not ta:
+        _lib.check(lib.iisan_gemm32(Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, ta, tb, 1, 0, _stream()), "gemm32")
+        torch.cuda.synchronize()
+        _close(C, torch.relu(ref + bias.double()), 1e-5, 1e-5, f"gemm32 relu {case}")
+    if ta and tb:
+        C.fill_(0.5)
+        _lib.check(lib.iisan_gemm32(Ad.data_ptr(), Bd.data_ptr(), None, C.data_ptr(), M, N, K, ta, tb, 0, 1, _stream()), "gemm32 acc")
+        torch.cuda.synchronize()
+        _close(C, ref + 0.5, 2e-5, 2e-5, f"gemm32 split-K accumulate {case}")
+    if not ta and not tb:
+        _lib.check(lib.iisan_gemm32(Ad.data_ptr(), Bd.data_ptr(), None, C.data_ptr(), M, N, K, 0, 0, 0, 0, _stream()), "gemm32 plain")
+        torch.cuda.synchronize()
+        _close(C, ref, 1e-5, 1e-5, f"gemm32 plain {case}")
+
+
+@pytest.mark.parametrize("variant", ["default", "gelu", "rmfirst"])
+def test_cached_model_loss_and_grads_match_reference(variant):
+    z, b, taps_cv, taps_tx, P, kw = gio.sidenet_full_inputs(variant)
+    args = helpers.make_args(adapter_activation="GELU" if variant == "gelu" else "RELU",
+                             remove_first="TRUE" if variant == "rmfirst" else "None")
+    model = helpers.build_model(args, 50, b.pop_prob, cached=True)
+    helpers.load_trainables(model, P)
+    model.eval()
+    bs, S = b.log_mask.shape
+    ids, lm = b.ids.cuda(), b.log_mask.cuda()
+    tc = taps_cv.view(bs, S + 1, 13, 768).cuda()
+    tt = taps_tx.view(bs, S + 1, 13, 768).cuda()
+    pre = variant + "/"
+    cv, (text, mm) = model.mm_encoder(tc, tt)
+    _close(cv, z[pre + "cv"], 2e-5, 2e-5, "cv")
+    _close(text, z[pre + "text"], 2e-5, 2e-5, "text")
+    _close(mm, z[pre + "mm"], 2e-5, 2e-5, "mm")
+    loss = model(ids.view(-1), tc, tt, lm, 0)
+    _close(loss, z[pre + "loss"], 2e-5, 0, "loss")
+    loss.backward()
+    n_checked = 0
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, f"no gradient for {n}"
+        _close(gio.sample_like_golden(p.grad), z[pre + "g/" + n], 5e-4, 2e-7, f"grad {n}")
+        gn = z[pre + "gn/" + n]
+        assert abs(float(p.grad.double().norm()) - gn[0]) <= 5e-4 * gn[0] + 1e-7, n
+        n_checked += 1
+    assert n_checked == len(P)
+
+
+def test_flat_trainer_adam_step_matches_reference():
+    z, b, taps_cv, taps_tx, P, kw = gio.sidenet_full_inputs("default")
+    args = helpers.make_args()
+    model = helpers.build_model(args, 50, b.pop_prob, cached=True)
+    helpers.load_trainables(model, P)
+    model.eval()
+    tr = trainer.FlatTrainer(model, args)
+    assert tr.flat.numel() == 4113877 and len(tr.seg_end) == 5
+    bs, S = b.log_mask.shape
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    loss = tr.step(b.ids.cuda().view(-1), taps_cv.view(bs, S + 1, 13, 768).cuda(), taps_tx.view(bs, S + 1, 13, 768).cuda(),
+                   b.log_mask.cuda())
+    _close(loss, z["default/loss"], 2e-5, 0, "loss")
+    # First Adam step: delta = -lr * g / (|g| + eps).  Where |g| is within a few orders of eps (1e-8) the update is
+    # sensitive to fp32 summation order of g itself, so: every element within 5 % of lr, 99.5 % within 0.2 %.
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            got = torch.from_numpy(gio.sample_like_golden(p.detach() - before[n])).double()
+            ref = torch.from_numpy(z["default/adam/" + n]).double()
+            scale = ref.abs().max().item()
+            err = (got - ref).abs()
+            assert err.max().item() <= 5e-2 * scale, f"adam delta {n}: max err {err.max().item():.3e} vs lr-scale {scale:.3e}"
+            assert (err > 2e-3 * scale).double().mean().item() <= 5e-3, f"adam delta {n}: too many elements off"
+
+
+def test_uncached_end_to_end_matches_reference():
+    z, vw, bw, b, P = gio.e2e_small_inputs()
+    args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8)
+    model = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+    helpers.load_trainables(model, P)
+    model.eval()
+    ids, lm = b.ids.cuda().view(-1), b.log_mask.cuda()
+    img, txt = b.images.cuda(), b.text.cuda()
+    cv, (text, mm) = model.mm_encoder(img, txt)
+    # fp16 encoder operands: tolerance from the measured budget: 1e-3 relative
+    real = (b.ids.view(-1) != 0)
+    for got, key in ((cv, "cv"), (text, "text_emb"), (mm, "mm")):
+        ref = torch.from_numpy(z[key])
+        rel = ((got.cpu().double() - ref.double())[real].norm() / ref.double()[real].norm()).item()
+        assert rel < 1e-3, f"{key}: rel {rel:.3e}"
+    loss = model(ids, img, txt, lm, 0)
+    rel = abs(loss.item() - float(z["loss"])) / float(z["loss"])
+    assert rel < 1e-3, f"loss {loss.item()} vs {float(z['loss'])} rel {rel:.3e}"
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            ref = torch.from_numpy(z["g/" + n]).double()
+            got = torch.from_numpy(gio.sample_like_golden(p.grad)).double()
+            assert (got - ref).norm() <= 5e-3 * ref.norm() + 1e-7, f"grad {n}: {(got - ref).norm()} vs {ref.norm()}"
+
+
+def test_eval_ranks_match_reference():
+    z, seqs, tables, P = gio.eval_inputs()
+    dev = "cuda"
+    item_emb = ops.LinearFn.apply(torch.cat(tables, 1).to(dev), P["com_dense.weight"].to(dev), P["com_dense.bias"].to(dev))
+    from iisan_amd.model import User_Encoder
+    ue = User_Encoder(int(z["item_num"]), 10, 64, 2, 0.1, 2).to(dev)
+    ue.load_state_dict({k[len("user_encoder."):]: v for k, v in P.items() if k.startswith("user_encoder.")})
+    S = 10
+    hist = torch.zeros(len(seqs), S, dtype=torch.int32)
+    tok = torch.zeros(len(seqs), S, dtype=torch.int64)
+    lm = torch.zeros(len(seqs), S)
+    tgt = torch.zeros(len(seqs), dtype=torch.int32)
+    for u, seq in enumerate(seqs):
+        t = seq[:-1]
+        hist[u, :len(t)] = torch.tensor(t, dtype=torch.int32)
+        tok[u, S - len(t):] = torch.tensor(t)
+        lm[u, S - len(t):] = 1
+        tgt[u] = seq[-1]
+    with torch.no_grad():
+        prec = ue(item_emb[tok.to(dev)], lm.to(dev), 0)[:, -1].contiguous()
+        ranks = ops.score_rank(prec, item_emb, hist.to(dev), tgt.to(dev)).cpu().long()
+    ref = torch.from_numpy(z["ranks"])
+    in_hist = torch.tensor([s[-1] in s[:-1] for s in seqs])
+    assert torch.equal(ranks[~in_hist], ref[~in_hist]), (ranks[~in_hist] - ref[~in_hist]).abs().max()
+    # oracle tie rule for targets that sit in their own history
+    item_cpu = item_emb.cpu()
+    o_ranks = O.eval_ranks(prec.cpu(), item_cpu, [torch.tensor(s[:-1]) for s in seqs], tgt.long())
+    assert torch.equal(ranks, o_ranks)
+    hit, ndcg = O.hit_ndcg(ranks)
+    assert abs(float(hit.mean()) - float(z["hit10"])) < 1e-6 and abs(float(ndcg.mean()) - float(z["ndcg10"])) < 1e-6
