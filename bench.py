@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the IISAN hot path on MI355X (contract: see the task statement / DESIGN.md §measurement).
+
+Metric (BASELINE.json): items/s (fwd+bwd+Adam) of Uncached IISAN, ViT-B/16 + BERT-base, Amazon-Scientific-shaped
+synthetic batches, bs=128 sequences per GPU (1408 item slots per step per GPU), weak scaling over N GPUs.
+One "step" = zero_grad -> frozen ViT+BERT forward with CLS taps (HIP, fp16 MFMA operands / fp32 accumulate) ->
+side network -> com_dense -> SASRec -> fused in-batch CE -> backward -> (N>1: one RCCL all-reduce of the flat
+gradient buffer) -> fused Adam.  Inputs are resident in HBM before the timed region.  ALL 1408 slots are encoded
+(padding slots included, like the reference); no dedup, no pruning.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_SLOT = 40.28e9          # ViT 35.126 + BERT 5.129 fwd + side net 3x0.008 (fwd+bwd)
+MFMA_PEAK = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=128, help="sequences per GPU (reference default bs x 11 item slots)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type of the frozen encoders")
+    ap.add_argument("--chunk", type=int, default=0, help="items per encoder chunk (0 = whole batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seed=5, budget_s=30.0):
+    """The CPU oracle (a port of the reference path, pinned against the reference's golden vectors) timed on this
+    host: Uncached IISAN, fp32, fwd+bwd+Adam, on a bounded sample (bs grows 2 -> 16 sequences while the time budget
+    allows; the largest completed step is reported)."""
+    from iisan_amd import synth, weights
+    from oracle import iisan_oracle as O
+    cores = min(os.cpu_count() or 1, 32)          # more threads than this only adds oversubscription on torch-CPU
+    torch.set_num_threads(cores)
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    P = {k: v.clone().requires_grad_(True) for k, v in weights.make_trainable_params(seed=99).items()}
+    layers = O.side_layer_list("1,3,5,7,9,11", False)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+
+    def step(b, i):
+        with torch.no_grad():
+            tc = O.vit_cls_taps(b.images, vw, weights.VIT_BASE)
+            tt = O.bert_cls_taps(b.text, bw, weights.BERT_BASE)
+        loss, _ = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, P, layers)
+        for p in P.values():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for k, p in P.items():
+                new, m[k], v2[k] = O.adam_step(p, p.grad, m[k], v2[k], i + 1, 1e-4)
+                p.copy_(new)
+
+    best, t_all, i = None, time.time(), 0
+    for bs in (2, 4, 8, 16):
+        b = synth.scientific_batch(bs=bs, seed=seed)
+        t0 = time.time()
+        step(b, i)
+        t = time.time() - t0
+        i += 1
+        best = (bs, t)
+        if (time.time() - t_all) + 2.2 * t > budget_s:       # the next size would not fit the budget
+            break
+    bs, t = best
+    return {"value": bs * 11 / t, "unit": "items/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/iisan_oracle.py, Uncached IISAN bs={bs} ({bs * 11} slots), fp32 torch-CPU on {cores} threads, "
+                      f"one fwd+bwd+Adam step ({t:.2f} s)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import helpers
+    from iisan_amd import _lib, encoders, synth, trainer, weights
+    lib = _lib.load()
+
+    args = helpers.make_args()
+    batch = synth.scientific_batch(bs=a.bs, seed=12345 + rank, device=dev, images_on_device=True)
+    vit_w, bert_w = weights.make_vit_weights(), weights.make_bert_weights()
+    model = helpers.build_model(args, synth.SCI_ITEM_NUM, batch.pop_prob.cpu(), vit_w, weights.VIT_BASE, bert_w,
+                                weights.BERT_BASE, cached=False, device=dev)
+    dt = encoders.DTYPE_NAMES[a.dtype]
+    model.mm_encoder.cv_encoder.dtype16 = dt
+    model.mm_encoder.bert_encoder.text_encoders["title"].dtype16 = dt
+    model.mm_encoder.cv_encoder.chunk_items = a.chunk
+    model.mm_encoder.bert_encoder.text_encoders["title"].chunk_items = a.chunk
+    model.train()
+    tr = trainer.FlatTrainer(model, args, world)
+    tr.broadcast_params()
+    ids = batch.ids.view(-1)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = tr.step(ids, batch.images, batch.text, batch.log_mask)
+    sync()
+    lib.iisan_timing_enable(1 if rank == 0 else 0)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(ids, batch.images, batch.text, batch.log_mask)
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.iisan_timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not torch.isfinite(loss).item():
+        raise SystemExit("bench.py: loss is not finite")
+
+    if rank == 0:
+        ms = C.c_double(0)
+        fl = C.c_double(0)
+        n_launch = lib.iisan_timing_collect(C.byref(ms), C.byref(fl))
+        slots = a.bs * 11
+        value = slots * world * a.steps / elapsed
+        gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        out = {
+            "metric": "items/s (fwd+bwd) ViT-B+BERT-B IISAN uncached, Scientific, bs=128",
+            "value": value, "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "Code_Uncached IISAN ViT-base+BERT-base, Amazon-Scientific-shaped synthetic batch, "
+                                   f"bs={a.bs}/GPU ({slots} item slots, all encoded), 1xMI355X per rank",
+                       "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / (MFMA_PEAK / 1e12), "traffic": None,
+                         "kernel": "gemm16_kernel (QKV/O/FC1/FC2/patch GEMMs of the frozen encoders)",
+                         "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
+                         "flop_per_launch": fl.value / max(n_launch, 1),
+                         "whole_step_frac": value / world * FLOP_PER_SLOT / MFMA_PEAK},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,12 @@ SIGNATURES = {
     "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
 }
 
+# bench-only helpers (not declared in include/iisan_hip.h)
+EXTRA_SIGNATURES = {
+    "iisan_timing_enable": (None, [i32]),
+    "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
 _lib = None
 
 
@@ -91,7 +97,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C iisan_amd/csrc`).  There is no CPU fallback for the IISAN hot path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is absent: loud by design
         fn.restype = res
         fn.argtypes = args

@@ -121,6 +121,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// per-launch HIP-event timing of the dominant kernel (timing.cpp); used by bench.py only
+bool iisan_timing_on();
+void iisan_timing_pre(hipStream_t s, double flops);
+void iisan_timing_post(hipStream_t s);
+
 // internal launchers shared between translation units -----------------------------------------------------------
 struct Gemm16Args {
     const void* A;      // [Mpad, K] 16-bit

@@ -178,7 +178,11 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(ceil_div(a.M, BM) * (a.N / BN) < (1ll << 31), "gemm16: grid too large");
     IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
-    return dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+    const bool timed = iisan_timing_on();
+    if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K);
+    const int rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+    if (timed) iisan_timing_post(s);
+    return rc;
 }
 
 extern "C" int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,
