@@ -77,6 +77,8 @@ SIGNATURES = {
 # bench-only helpers (not declared in include/iisan_hip.h)
 EXTRA_SIGNATURES = {
     "iisan_timing_enable": (None, [i32]),
+    "iisan_set_gemm16_variant": (None, [i32]),
+    "iisan_set_attn_debug": (None, [i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

@@ -1,4 +1,7 @@
 // Multi-head self-attention of the frozen encoders (head_dim 64): softmax(Q K^T / 8 + key_bias) V.
+// Input is the head-major QKV tensor [item][head][q|k|v][S][64] the QKV GEMM epilogue writes (EPI_QKVH16), so a
+// workgroup streams three contiguous ~25 KB blocks (measured: the token-major layout's 128-byte pieces at a 4.6 KB
+// stride capped the whole kernel at 1.85 TB/s of HBM reads).
 // Replaces HF ViTAttention / BertSelfAttention as reached from Code_Uncached/model/encoders.py:30,86
 // (SURVEY.md §8a U1/U2).  ≈4 % of the hot path's FLOPs; sequences are short (197 / 30 tokens), so one workgroup
 // owns one (item, head): K and V^T of that head live in LDS, each wave walks 16-query blocks.
@@ -15,132 +18,200 @@
 //     HF's additive mask, so an all-masked padding item attends uniformly; structural pad keys get -inf.
 #include "common.h"
 
+static int g_attn_dbg = 0;
+extern "C" void iisan_set_attn_debug(int v) { g_attn_dbg = v; }
+
 namespace {
 
-constexpr float MASK_MIN = -3.4028234663852886e38f;
+// masked keys carry this RAW score (before the log2(e)/8 scaling): every real score is absorbed by it, like HF's
+// additive fp32-min mask, and MASK_RAW * c2 stays finite
+constexpr float MASK_RAW = -1.0e38f;
 
+// One workgroup = one item x HPW consecutive heads, software-pipelined: while head h is being computed out of LDS,
+// the Q/K/V registers for head h+1 are already being filled from HBM (measured on the unpipelined version: the load
+// phase and the compute phase of a workgroup did not overlap at all and the kernel ran at 2.4 TB/s).
 template <typename T, int NT16>
-__global__ __launch_bounds__(256) void attention16_kernel(const typename T::elem* __restrict__ qkv,
-                                                          const float* __restrict__ key_bias,
-                                                          typename T::elem* __restrict__ ctx, int S, int heads) {
+__global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::elem* __restrict__ qkv,
+                                                             const float* __restrict__ key_bias,
+                                                             typename T::elem* __restrict__ ctx, int S, int heads, int hpw,
+                                                             int dbg) {
     typedef typename T::elem E;
     typedef typename T::v8 V8;
     typedef typename T::v4 V4;
     constexpr int SP = NT16 * 16;
-    constexpr int VT_LD = SP + 4;
+    // V^T row stride (elements): 132 dwords = 4 (mod 64) -> the two 8-byte reads of a half-wave (16 d-rows x 2 key
+    // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
+    constexpr int VT_LD = SP > 128 ? 264 : SP + 8;
+    constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
+    constexpr int KP = SP / 32;                       // K passes: 32 rows per pass
+    constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass
     __shared__ __attribute__((aligned(16))) char smem[SP * 128 + 64 * VT_LD * 2 + SP * 4];
     char* sK = smem;
     E* sVt = (E*)(smem + SP * 128);
     float* sKB = (float*)(smem + SP * 128 + 64 * VT_LD * 2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int item = blockIdx.x / heads, h = blockIdx.x - item * heads;
-    const int D = heads * 64, ld = 3 * D;
-    const E* base = qkv + (int64_t)item * S * ld + h * 64;
-
-    // ---- stage K (swizzled rows) and V^T ----
-    {
-        const int c = tid & 7;
-        for (int r = tid >> 3; r < SP; r += 32) {
-            V8 kv, vv;
-            if (r < S) {
-                kv = *(const V8*)(base + (int64_t)r * ld + D + c * 8);
-                vv = *(const V8*)(base + (int64_t)r * ld + 2 * D + c * 8);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    kv[e] = (E)0.f;
-                    vv[e] = (E)0.f;
-                }
-            }
-            *(V8*)(sK + r * 128 + ((c ^ (r & 7)) << 4)) = kv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VT_LD + r] = vv[e];
-        }
-        for (int r = tid; r < SP; r += 256)
-            sKB[r] = r >= S ? -2.0f : (key_bias ? key_bias[(int64_t)item * S + r] : 0.0f);
-    }
-    __syncthreads();
-
+    const int groups = heads / hpw;
+    const int item = blockIdx.x / groups, h0 = (blockIdx.x - item * groups) * hpw;
+    const int D = heads * 64;
     const int j = lane & 15, g = lane >> 4;
     const int nqb = (S + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += 4) {
-        const int sq = qb * 16 + j;
-        const int sqc = sq < S ? sq : S - 1;
-        V8 qf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const V8*)(base + (int64_t)sqc * ld + kk * 32 + g * 8);
+    const int c = tid & 7, r0 = tid >> 3;
 
-        // S^T tiles: lane holds query j, keys 16t + 4g + r
-        f4 sc[NT16];
+    V8 kreg[KP], vreg[VP][4], qnext[MAXQB][2];
+    auto load_head = [&](int h) {
+        // head-major input [item][head][q|k|v][S][64]: three contiguous blocks per (item, head)
+        const E* qb_ = qkv + ((int64_t)item * heads + h) * 3 * S * 64;
+        const E* kb_ = qb_ + (int64_t)S * 64;
+        const E* vb_ = kb_ + (int64_t)S * 64;
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MAXQB; ++i) {
+            int sq = (wave + 4 * i) * 16 + j;
+            sq = sq < S ? sq : S - 1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const V8 kf = *(const V8*)(sK + (t * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
-                acc = T::mfma(kf, qf[kk], acc);
-            }
-            const f4 kb = *(const f4*)(sKB + t * 16 + g * 4);
+            for (int kk = 0; kk < 2; ++kk) qnext[i][kk] = *(const V8*)(qb_ + sq * 64 + kk * 32 + g * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const int r = r0 + 32 * p;
+            if (r < S) kreg[p] = *(const V8*)(kb_ + r * 64 + c * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kreg[p][e] = (E)0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < VP; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = acc[r] * 0.125f;
-                sc[t][r] = kb[r] < -1.5f ? -INFINITY : (kb[r] < 0.f ? MASK_MIN : s);
+                const int key = (r0 + 32 * p) * 4 + r;
+                if (key < S) vreg[p][r] = *(const V8*)(vb_ + key * 64 + c * 8);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vreg[p][r][e] = (E)0.f;
+            }
+    };
+
+    load_head(h0);
+    for (int r = tid; r < SP; r += 256)
+        sKB[r] = r >= S ? -2.0f : (key_bias ? key_bias[(int64_t)item * S + r] : 0.0f);
+
+    // exp(s/8 - m) = exp2(acc * c2 - m2),  c2 = log2(e) / 8
+    const float c2 = 0.18033688011112042f;
+#pragma unroll 1
+    for (int hi = 0; hi < hpw; ++hi) {
+        const int h = h0 + hi;
+        if (hi > 0) __syncthreads();          // every wave is done reading the previous head's K / V^T
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const int r = r0 + 32 * p;
+            if (!(dbg & 16)) *(V8*)(sK + r * 128 + ((c ^ (r & 7)) << 4)) = kreg[p];
+        }
+        // V^T: a thread owns 4 consecutive keys x 8 head dims -> eight 8-byte LDS writes per pass
+#pragma unroll
+        for (int p = 0; p < VP; ++p) {
+            const int kg = r0 + 32 * p;
+            if (kg < SP / 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    V4 t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = vreg[p][r][e];
+                    if (!(dbg & 1)) *(V4*)(sVt + (c * 8 + e) * VT_LD + kg * 4) = t;
+                }
             }
         }
-        float mx = -INFINITY;
+        V8 qf[MAXQB][2];
 #pragma unroll
-        for (int t = 0; t < NT16; ++t)
+        for (int i = 0; i < MAXQB; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[t][r] - mx);
-                sc[t][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+            for (int kk = 0; kk < 2; ++kk) qf[i][kk] = qnext[i][kk];
+        __syncthreads();
+        if (hi + 1 < hpw) load_head(h + 1);   // in flight during this head's compute
 
-        // O^T = V^T · P^T
-        f4 o[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MAXQB; ++i) {
+            const int qb = wave + 4 * i;
+            if (qb >= nqb) break;
+            const int sq = qb * 16 + j;
+
+            // S^T tiles: lane holds query j, keys 16t + 4g + r (raw dot products; the 1/8 scale is folded into exp2)
+            // VALU diet (PMC: this kernel is VALU-bound, 1088 VALU instructions per 16-query block before): the
+            // mask select runs only on tiles that can contain masked/padded keys, scale+subtract is one fma, and
+            // exp2 is the bare v_exp_f32 (arguments <= 0, results in [0,1]: no range fix-up needed).
+            f4 sc[NT16];
 #pragma unroll
-        for (int kb = 0; kb < NT16 / 2; ++kb) {
-            V8 pf;
+            for (int t = 0; t < NT16; ++t) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (!(dbg & 2)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pf[e] = T::from_f32(sc[2 * kb][e]);
-                pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const V8 kf = *(const V8*)(sK + (t * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
+                        acc = T::mfma(kf, qf[i][kk], acc);
+                    }
+                }
+                if (key_bias != nullptr || t * 16 + 16 > S) {        // wave-uniform
+                    const f4 kb = *(const f4*)(sKB + t * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = kb[r] < -1.5f ? -INFINITY : (kb[r] < 0.f ? MASK_RAW : acc[r]);
+                }
+                sc[t] = acc;
             }
+            float mx = -INFINITY;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const E* vr = sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 4;
-                const V4 lo = *(const V4*)vr, hi = *(const V4*)(vr + 16);
-                V8 vf;
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = (sc[t][r] - mx) * c2;      // exact 0 at the maximum (an fma with -mx*c2 is not)
+                    const float p = (dbg & 32) ? a : __builtin_amdgcn_exp2f(a);
+                    sc[t][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+
+            // O^T = V^T · P^T
+            f4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NT16 / 2; ++kb) {
+                if ((dbg & 4) && kb > 0) break;
+                V8 pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    vf[e] = lo[e];
-                    vf[4 + e] = hi[e];
+                    pf[e] = T::from_f32(sc[2 * kb][e]);
+                    pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
                 }
-                o[dt] = T::mfma(vf, pf, o[dt]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const E* vr = sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 4;
+                    const V4 lo = *(const V4*)vr, hi2 = *(const V4*)(vr + 16);
+                    V8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vf[e] = lo[e];
+                        vf[4 + e] = hi2[e];
+                    }
+                    o[dt] = T::mfma(vf, pf, o[dt]);
+                }
             }
-        }
-        if (sq < S) {
-            E* op = ctx + ((int64_t)item * S + sq) * D + h * 64 + g * 4;
+            if (sq < S && !(dbg & 8)) {
+                E* op = ctx + ((int64_t)item * S + sq) * D + h * 64 + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                V4 ov;
+                for (int dt = 0; dt < 4; ++dt) {
+                    V4 ov;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = T::from_f32(o[dt][r] * inv);
-                *(V4*)(op + dt * 16) = ov;
+                    for (int r = 0; r < 4; ++r) ov[r] = T::from_f32(o[dt][r] * inv);
+                    *(V4*)(op + dt * 16) = ov;
+                }
             }
         }
     }
@@ -149,9 +220,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const typename T::elem
 template <typename T>
 int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, int S, int heads, hipStream_t s) {
     typedef typename T::elem E;
-    dim3 grid((unsigned)(items * heads)), block(256);
+    const int hpw = heads % 4 == 0 ? 4 : (heads % 3 == 0 ? 3 : (heads % 2 == 0 ? 2 : 1));   // heads per workgroup
+    dim3 grid((unsigned)(items * (heads / hpw))), block(256);
 #define IISAN_ATTN_CASE(NT)                                                                                        \
-    hipLaunchKernelGGL((attention16_kernel<T, NT>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads)
+    hipLaunchKernelGGL((attention16_kernel<T, NT>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg)
     if (S <= 32) IISAN_ATTN_CASE(2);
     else if (S <= 64) IISAN_ATTN_CASE(4);
     else if (S <= 128) IISAN_ATTN_CASE(8);

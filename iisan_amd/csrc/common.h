@@ -100,6 +100,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 6 fma instead of libm's branchy erff.
+// Used only where the result is rounded to a 16-bit operand anyway (FC1 epilogue of the frozen encoders).
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    const float erf_x = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_x);
+}
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -138,11 +148,18 @@ struct Gemm16Args {
     int32_t N, K;
     int32_t lda, ldw, ldo;
     int32_t patch_P;    // >0: row remap m -> (m/P)*(P+1) + 1 + m%P, += pos[1 + m%P]
+    int32_t qkv_S, qkv_heads;   // EPI_QKVH16: tokens per item and heads of the head-major QKV layout
+    int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
 };
-enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3 };
+enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4 };
+// EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
+// slice the attention kernel streams is then one contiguous block instead of 128-byte pieces at a 4.6 KB stride.
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
                         float* out32, int64_t rows, hipStream_t s);
+// x (+ delta16) -> [sum32 = x + delta] -> LayerNorm -> out16 / out32 (any output may be null; g == null: no LayerNorm)
+int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
+                            float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
 

@@ -19,24 +19,27 @@ struct EncBufs {
     void* H;        // [Tp, D] 16-bit: LayerNorm output, reused as the attention context
     void* QKV;      // [Tp, 3D] 16-bit
     void* F1;       // [Tp, max(F, patch_dim)] 16-bit: GELU(FC1) (and the patch matrix during embedding)
+    void* D16;      // [Tp, D] 16-bit: output of the O / FC2 GEMMs, added to the fp32 residual stream by the next LN kernel
     float* KB;      // [Mc, W] key bias (BERT)
 };
 
 size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int D, int F, int64_t kb_elems) {
-    const int64_t Tp = ceil_div(tokens, 128) * 128;
+    const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
     b.X = c.take<float>((size_t)Tp * D);
     b.H = c.take<uint16_t>((size_t)Tp * D);
     b.QKV = c.take<uint16_t>((size_t)Tp * 3 * D);
     b.F1 = c.take<uint16_t>((size_t)Tp * F);
+    b.D16 = c.take<uint16_t>((size_t)Tp * D);
     b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
     return c.off;
 }
 
 int gemm(int dt, int mode, const void* A, int K, const void* W, const float* bias, void* out, int N, const float* resid,
-         int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0) {
+         int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0, int qkv_S = 0, int qkv_heads = 0) {
     Gemm16Args a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = pos;
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = patch_P;
+    a.qkv_S = qkv_S; a.qkv_heads = qkv_heads;
     return launch_gemm16(dt, mode, a, s);
 }
 
@@ -99,19 +102,28 @@ extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* i
         IISAN_TRY(launch_vit_cls_rows(b.X, w->cls_token, w->pos_emb, mc, T, D, s));
         int k = tap_index(tap_layers, n_taps, 0);
         if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        // The O / FC2 GEMMs emit 16-bit deltas; the fp32 residual add is fused into the NEXT LayerNorm kernel
+        // (HBM-bound) instead of a read-modify-write GEMM epilogue.  `pending` = a delta not yet added to X.
+        const void* pending = nullptr;
         for (int l = 0; l < w->layers; ++l) {
             const iisan_layer_weights& L = w->layer[l];
-            // x += O(attn(LN1 x))
-            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln1_w, L.ln1_b, w->eps, b.H, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s));
+            // x (+= FC2 delta of layer l-1) ; h = LN1(x)            -> X is hidden state l
+            IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, L.ln1_w, L.ln1_b, w->eps, pending ? b.X : nullptr, b.H, nullptr, tok, s));
+            k = tap_index(tap_layers, n_taps, l);
+            if (k >= 0 && l > 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
             IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
-            IISAN_TRY(gemm(dt, EPI_RESID32, b.H, D, L.o_w, L.o_b, b.X, D, b.X, tok, s));
-            // x += FC2(gelu(FC1(LN2 x)))
-            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln2_w, L.ln2_b, w->eps, b.H, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
+            // x += O delta ; h = LN2(x)
+            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, b.X, b.H, nullptr, tok, s));
             IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_RESID32, b.F1, F, L.fc2_w, L.fc2_b, b.X, D, b.X, tok, s));
-            k = tap_index(tap_layers, n_taps, l + 1);
-            if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
+            pending = b.D16;
+        }
+        k = tap_index(tap_layers, n_taps, w->layers);
+        if (k >= 0) {   // last hidden state (before the final LayerNorm): only its CLS rows are needed
+            IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
+            IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
         }
     }
     return IISAN_OK;
@@ -152,14 +164,14 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
         for (int l = 0; l < w->layers; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // a = LN(x + O(attn(x)))
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s));
+            IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
             IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
-            IISAN_TRY(gemm(dt, EPI_RESID32, b.H, D, L.o_w, L.o_b, b.X, D, b.X, tok, s));
-            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln1_w, L.ln1_b, w->eps, b.H, b.X, tok, s));
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
+            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, b.X, tok, s));
             // x = LN(a + FC2(gelu(FC1 a)))
             IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_RESID32, b.F1, F, L.fc2_w, L.fc2_b, b.X, D, b.X, tok, s));
-            IISAN_TRY(launch_layernorm768(dt, b.X, L.ln2_w, L.ln2_b, w->eps, b.H, b.X, tok, s));
+            IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
+            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, b.X, tok, s));
             k = tap_index(tap_layers, n_taps, l + 1);
             if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
         }

@@ -131,11 +131,19 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                     v[4 + r] += b1[r];
                 }
             }
-            if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16) {
+            if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16 || EPI == EPI_QKVH16) {
                 V8 o;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = T::from_f32(EPI == EPI_GELU16 ? gelu_erf(v[r]) : v[r]);
-                *(V8*)((typename T::elem*)p.out + m * p.ldo + n) = o;
+                for (int r = 0; r < 8; ++r) o[r] = T::from_f32(EPI == EPI_GELU16 ? gelu_erf_fast(v[r]) : v[r]);
+                if constexpr (EPI == EPI_QKVH16) {
+                    const int Dm = p.qkv_heads * 64;
+                    const int64_t item = m / p.qkv_S;
+                    const int tok = (int)(m - item * p.qkv_S);
+                    const int which = n / Dm, hd = (n - which * Dm) >> 6, d = n & 63;
+                    *(V8*)((typename T::elem*)p.out + (((item * p.qkv_heads + hd) * 3 + which) * p.qkv_S + tok) * 64 + d) = o;
+                } else {
+                    *(V8*)((typename T::elem*)p.out + m * p.ldo + n) = o;
+                }
             } else if constexpr (EPI == EPI_RESID32) {
                 const float* rp = p.resid + m * p.ldo + n;
                 const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
@@ -164,6 +172,7 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
         case EPI_GELU16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_GELU16>), grid, block, 0, s, a); break;
         case EPI_RESID32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_RESID32>), grid, block, 0, s, a); break;
         case EPI_PATCH32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH32>), grid, block, 0, s, a); break;
+        case EPI_QKVH16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_QKVH16>), grid, block, 0, s, a); break;
         default: iisan_set_error("gemm16: bad epilogue mode %d", mode); return IISAN_EBADSHAPE;
     }
     IISAN_LAUNCH_OK();
@@ -172,15 +181,33 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 
 }  // namespace
 
+bool gemm16_p256_applicable(const Gemm16Args& a);
+int launch_gemm16_p256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+
+// 0 = auto (persistent 256x256 kernel when the shape allows and there is at least one tile per CU-ish), 1 = force the
+// 128x128 v1 kernel, 2 = force the 256x256 kernel.  Test/bench knob, not part of the product ABI.
+static int g_variant = 0;
+extern "C" void iisan_set_gemm16_variant(int v) { g_variant = v; }
+
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0, "gemm16: empty problem M=%lld N=%d K=%d", (long long)a.M, a.N, a.K);
     IISAN_CHECK_SHAPE(a.N % BN == 0 && a.K % BK == 0, "gemm16: N (%d) must be a multiple of %d and K (%d) of %d", a.N, BN, a.K, BK);
     IISAN_CHECK_SHAPE(ceil_div(a.M, BM) * (a.N / BN) < (1ll << 31), "gemm16: grid too large");
     IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
+    IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.N == 3 * 64 * a.qkv_heads),
+                      "gemm16: head-major QKV mode needs S, heads and N == 3*64*heads");
     const bool timed = iisan_timing_on();
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K);
-    const int rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+    const int var = g_variant & 0xff;
+    const bool big = var == 2 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    int rc;
+    if (big && gemm16_p256_applicable(a)) {
+        Gemm16Args b = a;
+        b.debug = g_variant >> 8;
+        rc = launch_gemm16_p256(dtype16, mode, b, s);
+    }
+    else rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
     if (timed) iisan_timing_post(s);
     return rc;
 }

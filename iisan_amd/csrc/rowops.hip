@@ -5,12 +5,15 @@
 
 namespace {
 
-// ---- LayerNorm over rows of 768 fp32 (HF nn.LayerNorm, eps inside the sqrt) ------------------------------------
+// ---- (residual add +) LayerNorm over rows of 768 fp32 (HF nn.LayerNorm, eps inside the sqrt) ----------------------
+// v = x + delta16 (delta optional: the 16-bit output of the preceding O / FC2 GEMM, so the fp32 read-modify-write of
+// the residual stream happens HERE, in an HBM-bound kernel, instead of stalling the MFMA pipeline in a GEMM epilogue);
+// sum32 <- v (optional, may alias x); out32 / out16 <- LN(v) (optional, out32 may alias x).  g == nullptr: add only.
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                           const float* __restrict__ b, float eps,
-                                                           typename T::elem* __restrict__ out16,
-                                                           float* __restrict__ out32, int64_t rows) {
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const typename T::elem* __restrict__ delta,
+                                                           const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                           float* sum32, typename T::elem* __restrict__ out16,
+                                                           float* out32, int64_t rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -20,8 +23,15 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         v[i] = *(const f4*)(xr + i * 256 + lane * 4);
+        if (delta) {
+            const typename T::v4 d = *(const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
+        }
+        if (sum32) *(f4*)(sum32 + row * 768 + i * 256 + lane * 4) = v[i];
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
+    if (!g) return;
     const float mean = wave_sum(s) * (1.0f / 768.0f);
     float q = 0.f;
 #pragma unroll
@@ -158,16 +168,21 @@ __global__ void cast16_kernel(const float* __restrict__ src, typename T::elem* _
 
 }  // namespace
 
-int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
-                        float* out32, int64_t rows, hipStream_t s) {
+int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
+                            float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
     if (rows <= 0) return IISAN_OK;
     dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
     if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, g, b, eps, (__bf16*)out16, out32, rows);
+        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, (const __bf16*)delta16, g, b, eps, sum32, (__bf16*)out16, out32, rows);
     else
-        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, g, b, eps, (_Float16*)out16, out32, rows);
+        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, (const _Float16*)delta16, g, b, eps, sum32, (_Float16*)out16, out32, rows);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
+}
+
+int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
+                        float* out32, int64_t rows, hipStream_t s) {
+    return launch_add_layernorm768(dtype16, x, nullptr, g, b, eps, nullptr, out16, out32, rows, s);
 }
 
 int launch_vit_im2col(int dtype16, const float* img, void* out, int64_t M, int C, int R, int p, hipStream_t s) {

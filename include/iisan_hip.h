@@ -192,13 +192,15 @@ int iisan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, con
  * Primitive kernels, exported for unit tests and micro-benchmarks only.
  * ---------------------------------------------------------------------------------------------------------- */
 /* C = epilogue(A[M,K] · W[N,K]^T + bias): 16-bit operands, fp32 accumulate.
- * mode 0: out16 = acc+bias     1: out16 = gelu_erf(acc+bias)     2: out32 = acc+bias+resid32 (resid may alias out) */
+ * mode 0: out16 = acc+bias     1: out16 = gelu_erf(acc+bias)     2: out32 = acc+bias+resid32 (resid may alias out)
+ * A must be readable for ceil(M/256)*256 rows (tiles are loaded whole; rows >= M are never stored). */
 int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,
                  const float* resid, int64_t M, int32_t N, int32_t K, void* stream);
 /* LayerNorm over rows of width 768: out16 (nullable) / out32 (nullable) */
 int iisan_layernorm768(int32_t dtype16, const float* x, const float* g, const float* b, float eps,
                        void* out16, float* out32, int64_t rows, void* stream);
-/* softmax(QK^T/sqrt(64) + key_bias)V per (item, head); qkv 16-bit [items*S, 3*H*64]; ctx 16-bit [items*S, H*64];
+/* softmax(QK^T/sqrt(64) + key_bias)V per (item, head); qkv 16-bit HEAD-MAJOR [items, H, 3 (q|k|v), S, 64] (what the QKV
+ * GEMM epilogue of the encoders writes); ctx 16-bit token-major [items*S, H*64];
  * key_bias fp32 [items,S] or NULL (values < 0 mark masked keys) */
 int iisan_attention16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int32_t S,
                       int32_t heads, void* stream);

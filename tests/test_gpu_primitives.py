@@ -17,7 +17,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _pad_rows(t, mult=128):
+def _pad_rows(t, mult=256):
     M = t.shape[0]
     Mp = (M + mult - 1) // mult * mult
     out = torch.zeros((Mp,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -25,11 +25,14 @@ def _pad_rows(t, mult=128):
     return out
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1000, 768, 3072), (517, 2304, 768)])
-def test_gemm16_vs_torch(lib, dt, mode, shape):
+@pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1000, 768, 3072), (517, 2304, 768), (70000, 768, 768)])
+def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
+    """variant 1 = 128x128 v1 kernel, 2 = persistent 256x256 kernel (falls back to v1 when N % 256 != 0)."""
     M, N, K = shape
+    lib.iisan_set_gemm16_variant(variant)
     g = torch.Generator().manual_seed(M * 7 + N + K + mode)
     # asymmetric, non-identity operands (catches transposed / permuted fragment layouts)
     A = (torch.randn(M, K, generator=g) * 0.5).to(T16[dt])
@@ -51,11 +54,12 @@ def test_gemm16_vs_torch(lib, dt, mode, shape):
     _lib.check(lib.iisan_gemm16(dt, mode, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
                                 rp.data_ptr() if rp is not None else None, M, N, K, _stream()), "gemm16")
     torch.cuda.synchronize()
+    lib.iisan_set_gemm16_variant(0)
     got = out.cpu().double()
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     tol = (2e-5 if mode == 2 else TOL[dt]) * scale
-    assert err <= tol, f"gemm16 dt={dt} mode={mode} {shape}: max err {err:.3e} > {tol:.3e}"
+    assert err <= tol, f"gemm16 variant={variant} dt={dt} mode={mode} {shape}: max err {err:.3e} > {tol:.3e}"
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -111,7 +115,8 @@ def test_attention16_vs_torch(lib, dt, case):
     ref = _attn_ref(qkv, kb, items, S, heads)
     ctx = torch.empty(items * S, D, dtype=T16[dt], device="cuda")
     kbd = kb.cuda() if kb is not None else None
-    qkvd = qkv.cuda()
+    # kernel input is head-major [items, heads, 3, S, 64]
+    qkvd = qkv.view(items, S, 3, heads, 64).permute(0, 3, 2, 1, 4).contiguous().cuda()
     _lib.check(lib.iisan_attention16(dt, qkvd.data_ptr(), kbd.data_ptr() if kbd is not None else None,
                                      ctx.data_ptr(), items, S, heads, _stream()), "attention16")
     torch.cuda.synchronize()

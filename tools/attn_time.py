@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Micro-benchmark / ablation of the encoder attention kernel (development aid)."""
+import sys, os, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iisan_amd import _lib
+lib = _lib.load()
+items, S, heads = 1408, 197, 12
+qkv = (torch.randn(items, heads, 3, S, 64, device="cuda")).half()
+ctx = torch.empty(items * S, heads * 64, device="cuda", dtype=torch.float16)
+st = torch.cuda.current_stream().cuda_stream
+flops = items * heads * 4.0 * S * S * 64
+for name, dbg in (("full", 0), ("no Vt write", 1), ("no K write", 16), ("no QK mfma", 2), ("no exp", 32), ("PV 1/7", 4), ("no store", 8),
+                  ("no QK,exp,PV", 2 + 32 + 4), ("staging only", 2 + 32 + 4 + 8), ("nothing", 1 + 16 + 2 + 32 + 4 + 8)):
+    lib.iisan_set_attn_debug(dbg)
+    for _ in range(2):
+        lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"{name:16s} {dt*1e6:8.1f} us  ({flops/dt/1e12:.0f} TF-equivalent)")
+lib.iisan_set_attn_debug(0)
