@@ -183,10 +183,14 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 
 bool gemm16_p256_applicable(const Gemm16Args& a);
 int launch_gemm16_p256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+bool gemm16_s256_applicable(int mode, const Gemm16Args& a);
+int launch_gemm16_s256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 
-// 0 = auto (persistent 256x256 kernel when the shape allows and there is at least one tile per CU-ish), 1 = force the
-// 128x128 v1 kernel, 2 = force the 256x256 kernel.  Test/bench knob, not part of the product ABI.
+// 0 = auto (persistent 256x256 kernels when the shape allows and there is at least half a tile per CU), 1 = force the
+// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel.
+// Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
+static int g_auto_staggered = 1;
 extern "C" void iisan_set_gemm16_variant(int v) { g_variant = v; }
 
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
@@ -200,9 +204,13 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const bool timed = iisan_timing_on();
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K);
     const int var = g_variant & 0xff;
-    const bool big = var == 2 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    const bool big = var == 2 || var == 3 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
-    if (big && gemm16_p256_applicable(a)) {
+    if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
+        Gemm16Args b = a;
+        b.debug = g_variant >> 8;
+        rc = launch_gemm16_s256(dtype16, mode, b, s);
+    } else if (big && gemm16_p256_applicable(a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
         rc = launch_gemm16_p256(dtype16, mode, b, s);

@@ -123,9 +123,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(25);
     }
 
+    bool waited = false;      // the DMA of this step was already waited for (before the previous tile's epilogue)
     for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps && !(p.debug & 2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!waited) {
+            if (s + 1 < nsteps && !(p.debug & 2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        waited = false;
         P256_BARRIER();
         const char* sA = smem + (s & 1) * P_STAGE_BYTES;
         const char* sW = sA + P_OP_BYTES;
@@ -165,6 +169,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
         const int ti = s / nk, kt = s - ti * nk;
         if (kt != nk - 1) continue;
 
+        // Retire the NEXT step's DMA before the epilogue stores enter the vmcnt queue (vmcnt counts stores too and a
+        // counted wait cannot tell them from loads): the stores then have a whole K-step to drain before the wait at
+        // the top of step s+2 has to cover them, instead of stalling step s+1 (ablation: stores cost QKV 20 %).
+        if (s + 1 < nsteps) {
+            if (s + 2 < nsteps && !(p.debug & 2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            waited = true;
+        }
         // ---- epilogue of output tile (pid + ti*G): lane (frow, fh) owns row .. + frow, 16 consecutive columns ----
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
@@ -204,7 +216,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
                         V8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = T::from_f32(EPI == EPI_GELU16 ? gelu_erf_fast(v[8 * h2 + e]) : v[8 * h2 + e]);
-                        *(V8*)(op + 8 * h2) = o;
+                        if (p.debug & 8) asm volatile("" ::"v"(o));           // ablation: math without the store
+                        else *(V8*)(op + 8 * h2) = o;
                     }
                 } else {
                     const float* rp;

@@ -25,12 +25,13 @@ def _pad_rows(t, mult=256):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1000, 768, 3072), (517, 2304, 768), (70000, 768, 768)])
 def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
-    """variant 1 = 128x128 v1 kernel, 2 = persistent 256x256 kernel (falls back to v1 when N % 256 != 0)."""
+    """variant 1 = 128x128 v1 kernel, 2 = persistent lock-step 256x256 kernel, 3 = persistent staggered 256x256 kernel
+    (16-bit epilogues only); 2 and 3 fall back when the shape does not qualify (N % 256 != 0, K < 128)."""
     M, N, K = shape
     lib.iisan_set_gemm16_variant(variant)
     g = torch.Generator().manual_seed(M * 7 + N + K + mode)
