@@ -13,13 +13,14 @@
 //        A:      R(s)      M(s)       R(s+1)     M(s+1)
 //        B:      M(s-1)    R(s)       M(s)       R(s+1)
 //
-// so on every SIMD one wave feeds the matrix pipe while its sibling reads LDS.  The 2-deep LDS ring is split into
-// four independently recycled pieces per K-step: the A-operand half of each group (private to that group: free as
-// soon as its R slot ends) and the two halves of the W tile (shared: free when B's R slot ends):
-//        A, start of M(s)   : DMA its A-half for step s+2      (3 slots of lead)
-//        A, start of R(s)   : DMA W rows   0..127 for step s+1 (2 slots)
-//        B, start of M(s)   : DMA W rows 128..255 and its A-half for step s+2 (2 / 3 slots)
-// with counted waits only (A: vmcnt(4) at the end of M; B: vmcnt(4) at the end of R, vmcnt(8) at the end of M).
+// so on every SIMD one wave feeds the matrix pipe while its sibling reads LDS.  ALL LDS-DMA is issued from READ
+// slots (issuing a `global_load_lds` costs the issuing wave ~60-180 cycles — measured: DMA issued from MFMA slots cost
+// 21 % of the loop — while a read slot has ~400 cycles of slack next to the sibling's 1024-cycle MFMA slot).  The ring
+// pieces are recycled independently: an A-operand half is private to its group (free when that group's R slot ends),
+// the W tile is shared (free when B's R slot ends):
+//        A, in R(s) (slot 2s)   : the whole W tile of step s+1                 (needed 2 slots later)
+//        B, in R(s) (slot 2s+1) : B's A-half of step s+1, then A's A-half of step s+2   (2 / 3 slots)
+// with counted waits only (A: vmcnt(0) at the end of M; B: vmcnt(8) at the end of R, vmcnt(4) at the end of M).
 // Tile walk, LDS swizzle, operand swap / W-row permutation and the 16-bit epilogues are those of gemm16_p256.hip.
 #include "common.h"
 
@@ -65,37 +66,39 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     const int nsteps = my_tiles * nk;
     if (nsteps == 0) return;
 
-    // staging: a group stages LDS rows grp*128 .. +127 of BOTH operand tiles; wave wq covers 32 of them as 4 chunks of
-    // 8 rows (1 KiB); lane -> row q = grp*128 + wq*32 + 8j + (lane>>3), physical slot lane&7 = logical ^ ((q>>1)&7)
-    int a_off[4], w_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = grp * 128 + wq * 32 + j * 8 + (lane >> 3);
-        const int slog = (lane & 7) ^ ((q >> 1) & 7);
-        a_off[j] = q * p.lda * 2 + slog * 16;
-        w_off[j] = nperm32s(q) * p.ldw * 2 + slog * 16;
-    }
+    // staging offsets, kept to 5 VGPRs: lane -> row-in-chunk r8 = lane>>3, physical slot lane&7; the logical slot is
+    // physical ^ ((row>>1)&7) = s0 ^ 4*(j&1) for chunk j of a 32-row-aligned run, s0 = (lane&7) ^ (lane>>4).
+    const int r8 = lane >> 3;
+    const int s0 = (lane & 7) ^ (lane >> 4);
+    const int slotx0 = s0 * 16, slotx1 = (s0 ^ 4) * 16;
+    const int rowA = r8 * p.lda * 2;                                             // A-operand: LDS row == global row
+    const int rowW = (16 * ((r8 >> 2) & 1) + (r8 & 3)) * p.ldw * 2;              // W: permuted rows (nperm32s)
     const char* Abase = (const char*)p.A;
     const char* Wbase = (const char*)p.W;
-    const int lds_rows_off = (grp * 128 + wq * 32) * 128;      // byte offset of this wave's 32 staged rows
 
-    auto issue_A = [&](int s) {       // this group's half of the A-operand tile of flat step s
+    // group B: half `h` (0 = A's rows 0..127, 1 = B's rows 128..255) of the A-operand tile of flat step s;
+    // wave wq stages rows h*128 + wq*32 .. +31 as 4 chunks of 8 rows
+    auto issue_Ahalf = [&](int s, int h) {
         const int ti = s / nk, kt = s - ti * nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n;
-        const char* Ag = Abase + ((int64_t)tm * SBM * p.lda + (int64_t)kt * SBK) * 2;
-        char* sA = smem + (s & 1) * S_STAGE_BYTES + lds_rows_off;
+        const int q0 = h * 128 + wq * 32;
+        const char* Ag = Abase + (((int64_t)tm * SBM + q0) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
+        char* sA = smem + (s & 1) * S_STAGE_BYTES + q0 * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(Ag + a_off[j], sA + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16(Ag + j * 8 * p.lda * 2 + ((j & 1) ? slotx1 : slotx0), sA + j * 1024);
     };
-    auto issue_W = [&](int s) {       // W-tile rows grp*128 .. +127 of flat step s
+    // group A: the whole W tile of flat step s; wave wq stages LDS rows wq*64 .. +63 as 8 chunks
+    auto issue_Wtile = [&](int s) {
         const int ti = s / nk, kt = s - ti * nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
-        const char* Wg = Wbase + ((int64_t)tn * SBN * p.ldw + (int64_t)kt * SBK) * 2;
-        char* sW = smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + lds_rows_off;
+        const int q0 = wq * 64;
+        const char* Wg = Wbase + (((int64_t)tn * SBN + q0) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
+        char* sW = smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + q0 * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(Wg + w_off[j], sW + j * 1024);
+        for (int j = 0; j < 8; ++j)      // chunk j: LDS rows q0+8j.. -> W rows q0 + 32*(j>>2) + 4*(j&3) + {0,16}+{0..3}
+            glds16(Wg + (32 * (j >> 2) + 4 * (j & 3)) * p.ldw * 2 + ((j & 1) ? slotx1 : slotx0), sW + j * 1024);
     };
 
     f16v acc[4][2];
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     const int fsw = (frow >> 1) & 7;
     int xoff[4], woff2[2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) xoff[mi] = (grp * 128 + mi * 32 + frow) * 128;
+    for (int mi = 0; mi < 4; ++mi) xoff[mi] = (grp * 128 + mi * 32 + frow) * 128;   // group g reads only its A-half
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) woff2[ni] = (wq * 64 + ni * 32 + frow) * 128;
 
@@ -185,32 +188,28 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias[i];
     __syncthreads();
 
-    // ---- prologue: everything of step 0 and the step-1 pieces that are not issued by the steady-state rules ----
+    // ---- prologue: step 0 and the pieces of step 1 that the steady-state rules would have issued before slot 0 ----
     if (grp == 0) {
-        issue_A(0);
-        issue_W(0);
-        if (nsteps > 1) { issue_A(1); S256_VMCNT(4); } else { S256_VMCNT(0); }
+        issue_Wtile(0);
+        S256_VMCNT(0);
     } else {
-        issue_W(0);
-        issue_A(0);
-        if (nsteps > 1) { issue_W(1); issue_A(1); S256_VMCNT(12); } else { S256_VMCNT(4); }   // W-half of step 0 landed
+        issue_Ahalf(0, 0);
+        issue_Ahalf(0, 1);
+        if (nsteps > 1) { issue_Ahalf(1, 0); S256_VMCNT(4); } else { S256_VMCNT(0); }
     }
-    S256_BARRIER();                                   // P: both W halves (and A's half) of step 0 are in LDS
+    S256_BARRIER();                                   // P: W(0) and both A-halves of step 0 are in LDS
 
     if (grp == 0) {
         // ================= group A =================
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s : R(s) ----
-            if (s + 1 < nsteps && !nodma) issue_W(s + 1);
+            if (s + 1 < nsteps && !nodma) issue_Wtile(s + 1);
             read_step(s);
             S256_LGKM0();
             S256_BARRIER();
             // ---- slot 2s+1 : M(s) ----
-            if (s + 2 < nsteps && !nodma) issue_A(s + 2);
             mfma_step();
-            // R(s+1) needs A-half(s+1) and W-half(s+1); only A-half(s+2) (4 loads) may stay in flight.  Done BEFORE the
-            // epilogue so its stores never sit inside a counted wait.
-            if (s + 2 < nsteps) S256_VMCNT(4); else S256_VMCNT(0);
+            S256_VMCNT(0);                            // W(s+1) landed (B's loads guarantee the A-halves)
             const int kt = s % nk;
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
@@ -218,18 +217,26 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         S256_BARRIER();                               // matches B's last slot
     } else {
         // ================= group B (one slot behind) =================
-        S256_VMCNT(8);                                // slot 0: A-half(0) of this group landed (step-1 pieces may fly)
-        S256_BARRIER();
+        S256_BARRIER();                               // slot 0
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s+1 : R(s) ----
+            if (!nodma) {
+                if (s + 1 < nsteps) issue_Ahalf(s + 1, 1);
+                if (s + 2 < nsteps) issue_Ahalf(s + 2, 0);
+            }
             read_step(s);
             S256_LGKM0();
-            S256_VMCNT(4);                            // W rows 128..255 of step s+1 landed (A reads them next slot)
+            // A's A-half of step s+1 (issued one R slot ago) must be in LDS before A's R(s+1) in the next slot; the
+            // loads issued in THIS slot may stay in flight
+            if (nodma) S256_VMCNT(0);
+            else if (s + 2 < nsteps) S256_VMCNT(8);
+            else if (s + 1 < nsteps) S256_VMCNT(4);
+            else S256_VMCNT(0);
             S256_BARRIER();
             // ---- slot 2s+2 : M(s) ----
-            if (s + 2 < nsteps && !nodma) { issue_W(s + 2); issue_A(s + 2); }
             mfma_step();
-            if (s + 2 < nsteps) S256_VMCNT(8); else S256_VMCNT(0);   // A-half(s+1) landed
+            // B's own A-half of step s+1 (first of the two batches issued in R(s)) before R(s+1)
+            if (s + 2 < nsteps && !nodma) S256_VMCNT(4); else S256_VMCNT(0);
             const int kt = s % nk;
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
