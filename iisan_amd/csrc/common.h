@@ -117,6 +117,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Counter-based dropout: the keep/scale factor of element `idx` at dropout site `site` is a pure function of
+// (seed, site, idx), so the backward pass regenerates the forward mask instead of storing it.  24-bit uniform from a
+// 64-bit mix (two rounds of xor-shift-multiply); tests/test_gpu_trainable.py re-implements it in numpy.
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr24, float inv_keep) {
+    uint64_t x = seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return ((uint32_t)(x >> 8) & 0xFFFFFFu) >= thr24 ? inv_keep : 0.f;
+}
+struct DropCfg {           // p == 0 (thr24 == 0): identity
+    uint64_t seed;
+    uint32_t site, thr24;
+    float inv_keep;
+};
+static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
+    DropCfg d;
+    d.seed = seed; d.site = site;
+    d.thr24 = p > 0.f ? (uint32_t)(p * 16777216.0f) : 0u;
+    d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16 (guide §5)
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -167,6 +190,7 @@ struct Gemm32Prob {
     const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;
     int64_t M; int32_t N; int64_t K;
     int32_t lda, ldb, ldc, ldr;
+    DropCfg drop;          // G32_DROPOUT: C = dropout(acc + bias [act]) (+ resid); element index = m*ldc + n
 };
 // flags for launch_gemm32
 enum {
@@ -177,6 +201,7 @@ enum {
     G32_ACCUM = 16,    // C += (atomicAdd; enables split-K)
     G32_MUL_RELU_MASK = 32,  // C = (.) * (act_src > 0)
     G32_MUL_GELU_GRAD = 64,  // C = (.) * gelu'(act_src)
-    G32_PREACT = 128,  // also store the pre-activation into act_src (as float* out) -- fwd of GELU adapters
+    G32_PREACT = 128,
+    G32_DROPOUT = 256, // scale by the dropout keep factor before the residual add  // also store the pre-activation into act_src (as float* out) -- fwd of GELU adapters
 };
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s);

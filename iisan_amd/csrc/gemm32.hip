@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 if (epi & G32_GELU) v = gelu_erf(v);
                 if (epi & G32_MUL_RELU_MASK) v = p.act_src[m * p.ldc + n] > 0.f ? v : 0.f;
                 if (epi & G32_MUL_GELU_GRAD) v *= gelu_erf_grad(p.act_src[m * p.ldc + n]);
+                if (epi & G32_DROPOUT) v *= drop_scale(p.drop.seed, p.drop.site, (uint64_t)(m * p.ldc + n), p.drop.thr24, p.drop.inv_keep);
                 if (p.resid && first_split) v += p.resid[m * p.ldr + n];
                 if constexpr ((FLAGS & G32_ACCUM) != 0)
                     atomicAdd(p.C + m * p.ldc + n, v);

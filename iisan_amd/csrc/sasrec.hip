@@ -9,8 +9,10 @@
 //   mask[q,k] = 0 if (k <= q and log_mask[k] != 0) else -1e9      (encoders.py:60-64)
 //
 // Projections/FFN run as fp32-MFMA GEMMs over all B*S rows (gemm32.hip); LayerNorm fwd/bwd are one-wave-per-row
-// shuffle kernels; the 10x10 attention is a thread-per-query-row kernel.  Dropout (reference drop_rate 0.1 in
-// training) is not implemented yet: cfg.dropout must be 0 (eval semantics), enforced loudly.
+// shuffle kernels; the 10x10 attention is a thread-per-query-row kernel.  Dropout (reference drop_rate in training:
+// after the embedding LayerNorm, on the attention probabilities, on the fc output and on the FFN output,
+// modules.py:17,31,62,94) uses the counter-based masks of common.h: site 0 = embedding, 1+3l / 2+3l / 3+3l = block l's
+// attention / fc / FFN; cfg.dropout == 0 is the exact eval path.
 #include "common.h"
 
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
@@ -25,7 +27,7 @@ constexpr int MAXE = 256;   // d_model up to 256 (multiple of 64)
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t b_rows, const float* __restrict__ g,
                                                          const float* __restrict__ beta, float eps, float* __restrict__ zsum,
-                                                         float* __restrict__ y, int64_t rows, int E) {
+                                                         float* __restrict__ y, int64_t rows, int E, DropCfg drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
     for (int i = 0; i < per; ++i) {
         const int c = i * 64 + lane;
         if (zsum) zsum[row * E + c] = v[i];
-        y[row * E + c] = (v[i] - mean) * rstd * g[c] + beta[c];
+        float o = (v[i] - mean) * rstd * g[c] + beta[c];
+        if (drop.thr24) o *= drop_scale(drop.seed, drop.site, (uint64_t)(row * E + c), drop.thr24, drop.inv_keep);
+        y[row * E + c] = o;
     }
 }
 
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // dgamma += sum dy*xhat ; dbeta += sum dy.  64 rows per block, block-level reduction, then atomics.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
                                                      const float* __restrict__ g, float eps, float* __restrict__ dz,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int E) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int E,
+                                                     DropCfg drop) {
     __shared__ float red[2][4][MAXE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = E / 64;
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z
         for (int i = 0; i < per; ++i) {
             v[i] = z[row * E + i * 64 + lane];
             d[i] = dy[row * E + i * 64 + lane];
+            if (drop.thr24) d[i] *= drop_scale(drop.seed, drop.site, (uint64_t)(row * E + i * 64 + lane), drop.thr24, drop.inv_keep);
             s += v[i];
         }
         const float mean = wave_sum(s) / (float)E;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z
 // attention forward: one thread per (b, h, q).  Q/K/V: [B*S, E] (head h = columns h*dh..); P: [B,H,S,S]; C: [B*S,E]
 __global__ void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                     const float* __restrict__ log_mask, float* __restrict__ P, float* __restrict__ C,
-                                    int64_t B, int S, int H, int dh) {
+                                    int64_t B, int S, int H, int dh, DropCfg drop) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H * S) return;
     const int q = (int)(i % S);
@@ -135,7 +141,8 @@ __global__ void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __
     float* pr = P + ((b * H + h) * S + q) * S;
     for (int k = 0; k < S; ++k) {
         sc[k] /= sum;
-        pr[k] = sc[k];
+        pr[k] = sc[k];                 // probabilities BEFORE dropout are kept for backward
+        if (drop.thr24) sc[k] *= drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep);
     }
     float* cr = C + (b * S + q) * E + h * dh;
     for (int e = 0; e < dh; ++e) {
@@ -150,8 +157,10 @@ __global__ void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __
 __global__ __launch_bounds__(64) void sas_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, const float* __restrict__ P,
                                                           const float* __restrict__ dC, float* __restrict__ dQ,
-                                                          float* __restrict__ dK, float* __restrict__ dV, int S, int H, int dh) {
+                                                          float* __restrict__ dK, float* __restrict__ dV, int S, int H, int dh,
+                                                          DropCfg drop) {
     __shared__ float dS[64 * 32];     // [(h*S + q)][k], S <= 32, H*S <= 64
+    __shared__ float sM[64 * 32];     // dropout keep factors of this sequence's probabilities
     const int64_t b = blockIdx.x;
     const int t = threadIdx.x;
     const int E = H * dh;
@@ -167,6 +176,9 @@ __global__ __launch_bounds__(64) void sas_attn_bwd_kernel(const float* __restric
             const float* vr = V + (b * S + k) * E + h * dh;
             float d = 0.f;
             for (int e = 0; e < dh; ++e) d += dc[e] * vr[e];
+            const float mk = drop.thr24 ? drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep) : 1.f;
+            sM[t * 32 + k] = mk;
+            d *= mk;                   // dP = dP_drop * mask/(1-p)
             dp[k] = d;
             dot += pr[k] * d;
         }
@@ -187,12 +199,18 @@ __global__ __launch_bounds__(64) void sas_attn_bwd_kernel(const float* __restric
             float ak = 0.f, av = 0.f;
             for (int qq = 0; qq < S; ++qq) {
                 ak += dS[(h * S + qq) * 32 + k] * Q[(b * S + qq) * E + h * dh + e];
-                av += P[((b * H + h) * S + qq) * S + k] * dC[(b * S + qq) * E + h * dh + e];
+                av += P[((b * H + h) * S + qq) * S + k] * sM[(h * S + qq) * 32 + k] * dC[(b * S + qq) * E + h * dh + e];
             }
             dk[e] = ak;
             dv[e] = av;
         }
     }
+}
+
+// out = in * dropout_keep_factor  (gradient of a dropped GEMM output)
+__global__ void drop_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, DropCfg drop) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] * drop_scale(drop.seed, drop.site, (uint64_t)i, drop.thr24, drop.inv_keep);
 }
 
 struct BlockBufs {
@@ -202,7 +220,7 @@ struct SasBufs {
     float* Z0;              // in + pos
     float* X0;              // LN(Z0)
     BlockBufs blk[8];
-    float *dA, *dB, *dQ, *dK, *dV, *dH;     // backward scratch
+    float *dA, *dB, *dQ, *dK, *dV, *dH, *dG;     // backward scratch
 };
 
 void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
@@ -219,6 +237,7 @@ void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
     b.dA = c.take<float>(T * E); b.dB = c.take<float>(T * E);
     b.dQ = c.take<float>(T * E); b.dK = c.take<float>(T * E); b.dV = c.take<float>(T * E);
     b.dH = c.take<float>(T * 4 * E);
+    b.dG = c.take<float>(T * E);
 }
 
 int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {
@@ -227,8 +246,7 @@ int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {
     IISAN_CHECK_SHAPE(cfg->heads > 0 && cfg->emb % cfg->heads == 0, "sasrec: heads %d does not divide d_model %d", cfg->heads, cfg->emb);
     IISAN_CHECK_SHAPE(cfg->seq >= 1 && cfg->seq <= 32 && cfg->seq * cfg->heads <= 64, "sasrec: seq %d x heads %d unsupported", cfg->seq, cfg->heads);
     IISAN_CHECK_SHAPE(cfg->blocks >= 1 && cfg->blocks <= 8, "sasrec: %d blocks unsupported", cfg->blocks);
-    IISAN_CHECK_SHAPE(cfg->dropout == 0.f, "sasrec: dropout %.3f requested but only eval semantics (dropout 0) are "
-                      "implemented in this round", cfg->dropout);
+    IISAN_CHECK_SHAPE(cfg->dropout >= 0.f && cfg->dropout < 1.f, "sasrec: dropout %.3f out of range", cfg->dropout);
     return IISAN_OK;
 }
 
@@ -268,7 +286,10 @@ extern "C" int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, con
     const int64_t T = B * S;
     auto W = [&](int i) { return (const float*)params[i]; };
     const dim3 ln_grid((unsigned)ceil_div(T, 4)), blk(256);
-    hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, x, W(0), (int64_t)S, W(1), W(2), 1e-6f, b.Z0, b.X0, T, E);
+    const float pd = cfg->dropout;
+    const DropCfg nodrop = make_drop(0, 0, 0.f);
+    hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, x, W(0), (int64_t)S, W(1), W(2), 1e-6f, b.Z0, b.X0, T, E,
+                       make_drop(cfg->seed, 0, pd));
     IISAN_LAUNCH_OK();
     const float* xin = b.X0;
     for (int l = 0; l < cfg->blocks; ++l) {
@@ -277,20 +298,22 @@ extern "C" int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, con
                             prob(xin, E, W(pb(l, 2)), E, nullptr, k.V, E, T, E, E)};
         IISAN_TRY(launch_gemm32(pr, 3, 0, s));
         hipLaunchKernelGGL(sas_attn_fwd_kernel, dim3((unsigned)ceil_div(B * H * S, 128)), dim3(128), 0, s, k.Q, k.K, k.V,
-                           log_mask, k.P, k.C, B, S, H, dh);
+                           log_mask, k.P, k.C, B, S, H, dh, make_drop(cfg->seed, 1 + 3 * l, pd));
         IISAN_LAUNCH_OK();
-        Gemm32Prob pf = prob(k.C, E, W(pb(l, 3)), E, nullptr, k.Zattn, E, T, E, E, xin);        // x + fc(ctx)
-        IISAN_TRY(launch_gemm32(&pf, 1, 0, s));
+        Gemm32Prob pf = prob(k.C, E, W(pb(l, 3)), E, nullptr, k.Zattn, E, T, E, E, xin);        // x + drop(fc(ctx))
+        pf.drop = make_drop(cfg->seed, 2 + 3 * l, pd);
+        IISAN_TRY(launch_gemm32(&pf, 1, pd > 0.f ? G32_DROPOUT : 0, s));
         hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, k.Zattn, (const float*)nullptr, (int64_t)0, W(pb(l, 4)),
-                           W(pb(l, 5)), 1e-6f, (float*)nullptr, k.X1, T, E);
+                           W(pb(l, 5)), 1e-6f, (float*)nullptr, k.X1, T, E, nodrop);
         IISAN_LAUNCH_OK();
         Gemm32Prob p1 = prob(k.X1, E, W(pb(l, 6)), E, W(pb(l, 7)), k.Hf, 4 * E, T, 4 * E, E);   // relu(W1 x + b1)
         IISAN_TRY(launch_gemm32(&p1, 1, G32_RELU, s));
-        Gemm32Prob p2 = prob(k.Hf, 4 * E, W(pb(l, 8)), 4 * E, W(pb(l, 9)), k.Zffn, E, T, E, 4 * E, k.X1);
-        IISAN_TRY(launch_gemm32(&p2, 1, 0, s));
+        Gemm32Prob p2 = prob(k.Hf, 4 * E, W(pb(l, 8)), 4 * E, W(pb(l, 9)), k.Zffn, E, T, E, 4 * E, k.X1);   // x1 + drop(ffn)
+        p2.drop = make_drop(cfg->seed, 3 + 3 * l, pd);
+        IISAN_TRY(launch_gemm32(&p2, 1, pd > 0.f ? G32_DROPOUT : 0, s));
         float* out = (l == cfg->blocks - 1) ? y : k.X2;
         hipLaunchKernelGGL(add_ln_fwd_kernel, ln_grid, blk, 0, s, k.Zffn, (const float*)nullptr, (int64_t)0, W(pb(l, 10)),
-                           W(pb(l, 11)), 1e-6f, (float*)nullptr, out, T, E);
+                           W(pb(l, 11)), 1e-6f, (float*)nullptr, out, T, E, nodrop);
         IISAN_LAUNCH_OK();
         xin = out;
     }
@@ -314,22 +337,31 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
     auto W = [&](int i) { return (const float*)params[i]; };
     auto G = [&](int i) { return (float*)grads[i]; };
     const dim3 lnb_grid((unsigned)ceil_div(T, 64)), blk(256);
+    const float pd = cfg->dropout;
+    const DropCfg nodrop = make_drop(0, 0, 0.f);
+    const unsigned ew_grid = (unsigned)(ceil_div(T * E, 256) < 2048 ? ceil_div(T * E, 256) : 2048);
     const float* dcur = dy;        // gradient wrt the current block's output X2
     for (int l = cfg->blocks - 1; l >= 0; --l) {
         BlockBufs& k = b.blk[l];
         const float* xin = l == 0 ? b.X0 : b.blk[l - 1].X2;
         // X2 = LN(Zffn): dZffn -> dA
-        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zffn, dcur, W(pb(l, 10)), 1e-6f, b.dA, G(pb(l, 10)), G(pb(l, 11)), T, E);
+        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zffn, dcur, W(pb(l, 10)), 1e-6f, b.dA, G(pb(l, 10)), G(pb(l, 11)), T, E, nodrop);
         IISAN_LAUNCH_OK();
-        // Zffn = X1 + Hf W2^T + b2
-        Gemm32Prob p = prob(b.dA, E, W(pb(l, 8)), 4 * E, nullptr, b.dH, 4 * E, T, 4 * E, E, nullptr, k.Hf);
-        IISAN_TRY(launch_gemm32(&p, 1, G32_TB | G32_MUL_RELU_MASK, s));                       // dH = (dA·W2) ⊙ [Hf>0]
-        p = prob(b.dA, E, k.Hf, 4 * E, nullptr, G(pb(l, 8)), 4 * E, E, 4 * E, T);
-        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dW2 += dA^T·Hf
+        // Zffn = X1 + drop(Hf W2^T + b2): the FFN branch sees dA times the forward keep factors
+        const float* gF = b.dA;
+        if (pd > 0.f) {
+            hipLaunchKernelGGL(drop_apply_kernel, dim3(ew_grid), dim3(256), 0, s, b.dA, b.dG, T * E, make_drop(cfg->seed, 3 + 3 * l, pd));
+            IISAN_LAUNCH_OK();
+            gF = b.dG;
+        }
+        Gemm32Prob p = prob(gF, E, W(pb(l, 8)), 4 * E, nullptr, b.dH, 4 * E, T, 4 * E, E, nullptr, k.Hf);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB | G32_MUL_RELU_MASK, s));                       // dH = (g·W2) ⊙ [Hf>0]
+        p = prob(gF, E, k.Hf, 4 * E, nullptr, G(pb(l, 8)), 4 * E, E, 4 * E, T);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dW2 += g^T·Hf
         p = prob(b.dH, 4 * E, k.X1, E, nullptr, G(pb(l, 6)), E, 4 * E, E, T);
         IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dW1 += dH^T·X1
         {
-            const float* X[2] = {b.dA, b.dH};
+            const float* X[2] = {gF, b.dH};
             float* O[2] = {G(pb(l, 9)), G(pb(l, 7))};
             int64_t Ms[2] = {T, T};
             int32_t Ns[2] = {E, 4 * E}, lds[2] = {E, 4 * E};
@@ -338,14 +370,21 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
         p = prob(b.dH, 4 * E, W(pb(l, 6)), E, nullptr, b.dB, E, T, E, 4 * E, b.dA);
         IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dX1 = dA + dH·W1
         // X1 = LN(Zattn): dZattn -> dA
-        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zattn, b.dB, W(pb(l, 4)), 1e-6f, b.dA, G(pb(l, 4)), G(pb(l, 5)), T, E);
+        hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, k.Zattn, b.dB, W(pb(l, 4)), 1e-6f, b.dA, G(pb(l, 4)), G(pb(l, 5)), T, E, nodrop);
         IISAN_LAUNCH_OK();
-        // Zattn = xin + C Wfc^T
-        p = prob(b.dA, E, W(pb(l, 3)), E, nullptr, b.dB, E, T, E, E);
-        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dC = dA·Wfc
-        p = prob(b.dA, E, k.C, E, nullptr, G(pb(l, 3)), E, E, E, T);
-        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dWfc += dA^T·C
-        hipLaunchKernelGGL(sas_attn_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, k.Q, k.K, k.V, k.P, b.dB, b.dQ, b.dK, b.dV, S, H, dh);
+        // Zattn = xin + drop(C Wfc^T)
+        const float* gA = b.dA;
+        if (pd > 0.f) {
+            hipLaunchKernelGGL(drop_apply_kernel, dim3(ew_grid), dim3(256), 0, s, b.dA, b.dG, T * E, make_drop(cfg->seed, 2 + 3 * l, pd));
+            IISAN_LAUNCH_OK();
+            gA = b.dG;
+        }
+        p = prob(gA, E, W(pb(l, 3)), E, nullptr, b.dB, E, T, E, E);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dC = g·Wfc
+        p = prob(gA, E, k.C, E, nullptr, G(pb(l, 3)), E, E, E, T);
+        IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dWfc += g^T·C
+        hipLaunchKernelGGL(sas_attn_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, k.Q, k.K, k.V, k.P, b.dB, b.dQ, b.dK, b.dV, S, H, dh,
+                           make_drop(cfg->seed, 1 + 3 * l, pd));
         IISAN_LAUNCH_OK();
         {
             Gemm32Prob pr[3] = {prob(b.dQ, E, xin, E, nullptr, G(pb(l, 0)), E, E, E, T), prob(b.dK, E, xin, E, nullptr, G(pb(l, 1)), E, E, E, T),
@@ -357,9 +396,7 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
         IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
         p = prob(b.dK, E, W(pb(l, 1)), E, nullptr, b.dA, E, T, E, E, b.dA);
         IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
-        float* dst = (l == 0) ? b.dB : (float*)b.blk[l - 1].X2;   // X2 of the block below is dead once consumed: reuse
-        // keep it simple and safe: always write the block-input gradient into dQ (free after the three products)
-        dst = b.dQ;
+        float* dst = b.dQ;      // free after the three weight-gradient products
         p = prob(b.dV, E, W(pb(l, 2)), E, nullptr, dst, E, T, E, E, b.dA);
         IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));
         // dQ now holds d(xin); move it to dK so the next iteration can reuse dQ/dA/dB freely
@@ -367,7 +404,7 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
         dcur = b.dK;
     }
     // X0 = LN(Z0), Z0 = x + pos
-    hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, b.Z0, dcur, W(1), 1e-6f, dx, G(1), G(2), T, E);
+    hipLaunchKernelGGL(ln_bwd_kernel, lnb_grid, blk, 0, s, b.Z0, dcur, W(1), 1e-6f, dx, G(1), G(2), T, E, make_drop(cfg->seed, 0, pd));
     IISAN_LAUNCH_OK();
     {
         const float* X[1] = {dx};

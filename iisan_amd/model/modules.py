@@ -70,7 +70,9 @@ class TransformerEncoder(nn.Module):               # modules.py:79-96
     def forward(self, input_embs, log_mask, att_mask=None):
         """`att_mask` is accepted for signature parity (`modules.py:89`) and ignored: the kernel derives the causal +
         padding mask from `log_mask` exactly as `User_Encoder.forward` builds it (`encoders.py:60-64`)."""
-        cfg = ops.make_sasrec_cfg(input_embs.shape[1], self.d_model, self.n_heads, self.n_layers, 0.0)
+        p = self.p_drop if self.training else 0.0          # nn.Dropout semantics: active in train() only
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # CPU generator: no device sync
+        cfg = ops.make_sasrec_cfg(input_embs.shape[1], self.d_model, self.n_heads, self.n_layers, p, seed)
         return ops.SasrecFn.apply(cfg, input_embs, log_mask, *self.abi_params())
 
 

@@ -177,13 +177,18 @@ def sasrec_mask(log_mask: Tensor) -> Tensor:
 
 
 def sasrec(x: Tensor, log_mask: Tensor, P: Dict[str, Tensor], heads: int, n_layers: int,
-           pre: str = "user_encoder.transformer_encoder.") -> Tensor:
-    """x [B,S,E] -> [B,S,E]; dropout is identity (eval / p=0)."""
+           pre: str = "user_encoder.transformer_encoder.", drop: Dict[int, Tensor] | None = None) -> Tensor:
+    """x [B,S,E] -> [B,S,E].  `drop` (optional) maps a dropout site to its keep-factor tensor (0 or 1/(1-p)) so a test
+    can inject the exact masks the HIP path generates; sites follow the reference's four nn.Dropout calls
+    (modules.py:17,31,62,94): 0 = after the embedding LayerNorm [B,S,E]; 1+3l = attention probabilities of block l
+    [B,H,S,S]; 2+3l = fc output [B,S,E]; 3+3l = FFN output [B,S,E].  None = identity (eval)."""
     B, S, E = x.shape
     d = E // heads
     mask = sasrec_mask(log_mask)
+    dr = (lambda site, t: t * drop[site]) if drop is not None else (lambda site, t: t)
     x = F.layer_norm(x + P[pre + "position_embedding.weight"][:S][None], (E,),
                      P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], 1e-6)       # modules.py:89-93
+    x = dr(0, x)
     for l in range(n_layers):
         a = pre + f"transformer_blocks.{l}.multi_head_attention."
         f = pre + f"transformer_blocks.{l}.feed_forward."
@@ -191,12 +196,12 @@ def sasrec(x: Tensor, log_mask: Tensor, P: Dict[str, Tensor], heads: int, n_laye
         k = F.linear(x, P[a + "w_K.weight"]).view(B, S, heads, d).transpose(1, 2)
         v = F.linear(x, P[a + "w_V.weight"]).view(B, S, heads, d).transpose(1, 2)
         s = torch.matmul(q, k.transpose(-1, -2)) / (d ** 0.5) + mask                       # modules.py:28-30
-        c = torch.matmul(torch.softmax(s, -1), v).transpose(1, 2).reshape(B, S, E)
-        x = F.layer_norm(x + F.linear(c, P[a + "fc.weight"]), (E,),
+        c = torch.matmul(dr(1 + 3 * l, torch.softmax(s, -1)), v).transpose(1, 2).reshape(B, S, E)
+        x = F.layer_norm(x + dr(2 + 3 * l, F.linear(c, P[a + "fc.weight"])), (E,),
                          P[a + "layer_norm.weight"], P[a + "layer_norm.bias"], 1e-6)       # modules.py:60-64
         h = F.linear(F.relu(F.linear(x, P[f + "w_1.weight"], P[f + "w_1.bias"])),
                      P[f + "w_2.weight"], P[f + "w_2.bias"])
-        x = F.layer_norm(x + h, (E,), P[f + "layer_norm.weight"], P[f + "layer_norm.bias"], 1e-6)  # modules.py:15-18
+        x = F.layer_norm(x + dr(3 + 3 * l, h), (E,), P[f + "layer_norm.weight"], P[f + "layer_norm.bias"], 1e-6)  # modules.py:15-18
     return x
 
 

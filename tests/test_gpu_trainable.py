@@ -153,6 +153,7 @@ def test_eval_ranks_match_reference():
     from iisan_amd.model import User_Encoder
     ue = User_Encoder(int(z["item_num"]), 10, 64, 2, 0.1, 2).to(dev)
     ue.load_state_dict({k[len("user_encoder."):]: v for k, v in P.items() if k.startswith("user_encoder.")})
+    ue.eval()                                   # eval_model() runs under model.eval(): SASRec dropout off
     S = 10
     hist = torch.zeros(len(seqs), S, dtype=torch.int32)
     tok = torch.zeros(len(seqs), S, dtype=torch.int64)
@@ -176,3 +177,55 @@ def test_eval_ranks_match_reference():
     assert torch.equal(ranks, o_ranks)
     hit, ndcg = O.hit_ndcg(ranks)
     assert abs(float(hit.mean()) - float(z["hit10"])) < 1e-6 and abs(float(ndcg.mean()) - float(z["ndcg10"])) < 1e-6
+
+
+def _drop_factors(seed, site, n, p):
+    """numpy re-implementation of drop_scale() in iisan_amd/csrc/common.h."""
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + np.uint64(site) * np.uint64(0x9E3779B97F4A7C15) + idx * np.uint64(0xD1B54A32D192ED03)
+        for _ in range(2):
+            x ^= x >> np.uint64(32)
+            x = (x * np.uint64(0xD6E8FEB86659FD93)) & M64
+        x ^= x >> np.uint64(32)
+    u = ((x >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.int64)
+    thr = int(np.float32(p) * np.float32(16777216.0))
+    return torch.from_numpy(np.where(u >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32))
+
+
+def test_sasrec_dropout_matches_oracle_with_the_same_masks():
+    """Training-mode SASRec (reference drop_rate 0.1): forward AND backward against the oracle fed with the masks the
+    counter-based generator of the HIP path produces."""
+    B, S, E, H, L, p, seed = 37, 10, 64, 2, 2, 0.1, 123456789012345
+    g = torch.Generator().manual_seed(5)
+    P = {k: v for k, v in gio.weights.make_trainable_params(seed=99).items() if k.startswith("user_encoder.")}
+    x = torch.randn(B, S, E, generator=g)
+    lm = (torch.rand(B, S, generator=g) > 0.3).float()
+    lm[:, -1] = 1
+    masks = {0: _drop_factors(seed, 0, B * S * E, p).view(B, S, E)}
+    for l in range(L):
+        masks[1 + 3 * l] = _drop_factors(seed, 1 + 3 * l, B * H * S * S, p).view(B, H, S, S)
+        masks[2 + 3 * l] = _drop_factors(seed, 2 + 3 * l, B * S * E, p).view(B, S, E)
+        masks[3 + 3 * l] = _drop_factors(seed, 3 + 3 * l, B * S * E, p).view(B, S, E)
+    keep = float(torch.cat([m.reshape(-1) for m in masks.values()]).ne(0).float().mean())
+    assert abs(keep - (1 - p)) < 0.01
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = O.sasrec(xo, lm, Po, H, L, drop=masks)
+    w = torch.randn(B, S, E, generator=g)
+    (yo * w).sum().backward()
+    order = ops.sasrec_param_order(L)
+    params = [P["user_encoder.transformer_encoder." + k].cuda().requires_grad_(True) for k in order]
+    xd = x.cuda().requires_grad_(True)
+    cfg = ops.make_sasrec_cfg(S, E, H, L, p, seed)
+    y = ops.SasrecFn.apply(cfg, xd, lm.cuda(), *params)
+    (y * w.cuda()).sum().backward()
+    _close(y, yo.detach(), 2e-5, 2e-5, "dropout forward")
+    _close(xd.grad, xo.grad, 2e-4, 1e-6, "dropout dx")
+    for k, t in zip(order, params):
+        _close(t.grad, Po["user_encoder.transformer_encoder." + k].grad, 3e-4, 1e-6, f"dropout grad {k}")
+    # eval mode stays the deterministic path
+    cfg0 = ops.make_sasrec_cfg(S, E, H, L, 0.0, 0)
+    y0 = ops.SasrecFn.apply(cfg0, x.cuda(), lm.cuda(), *[t.detach() for t in params])
+    _close(y0, O.sasrec(x, lm, P, H, L), 2e-5, 2e-5, "eval forward")
