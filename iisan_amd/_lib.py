@@ -38,7 +38,8 @@ class BertWeights(C.Structure):
 class SideCfg(C.Structure):
     _fields_ = [("n_side", i32), ("dim_cv", i32), ("dim_text", i32), ("down", i32), ("emb", i32),
                 ("gated", i32), ("gelu", i32), ("remove_first", i32), ("tap_stride_cv", i32),
-                ("tap_stride_text", i32), ("tap_index", i32 * MAX_SIDE), ("first_index", i32)]
+                ("tap_stride_text", i32), ("tap_index", i32 * MAX_SIDE), ("first_index", i32),
+                ("versa", i32), ("n_side_text", i32), ("tap_index_text", i32 * MAX_SIDE), ("first_index_text", i32)]
 
 
 class SasrecCfg(C.Structure):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "iisan_bert_forward_taps_ws_bytes": (sz, [C.POINTER(BertWeights), i64, i32, i64]),
     "iisan_bert_forward_taps": (i32, [C.POINTER(BertWeights), vp, i64, i32, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_side_net_ws_bytes": (sz, [C.POINTER(SideCfg), i64]),
+    "iisan_side_net_num_params": (i32, [C.POINTER(SideCfg)]),
     "iisan_side_net_fwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
     "iisan_side_net_bwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, C.POINTER(vp), vp, sz, vp]),
     "iisan_linear_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),

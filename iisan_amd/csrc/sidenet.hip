@@ -1,15 +1,20 @@
 // Intra-/inter-modal Side Adapted Network: forward and backward executors + the fusion kernels.
-// Replaces IISANAdaptedMModel.forward (Code_Uncached/model/model.py:209-271; Code_Cached/model/model.py:300-349)
-// and the AdapterBlock it stacks (Code_*/model/modules.py:98-116), plus the backward PyTorch autograd derives.
+// Replaces IISANAdaptedMModel.forward of all three reference variants and the AdapterBlock it stacks
+// (Code_*/model/modules.py:98-116), plus the backward PyTorch autograd derives:
+//   * Uncached  Code_Uncached/model/model.py:209-271      * Cached  Code_Cached/model/model.py:300-349
+//   * Versa     Code_Cached_Asym/model/model.py:322-429  (towers of different depth and width: the longer tower first
+//     runs its surplus leading SANBs alone — "group layer-drop", :353-378 — then aligned pairs; the wider modality's
+//     tap goes through a per-pair Linear(max_dim -> min_dim) — "dim-align", :400-411 — before the inter-modal sum)
 //
-//   for k in 0..n-1:   F_cv = g·tap_v[k] + (1-g)·cv      F_t = g·tap_t[k] + (1-g)·text      F_mm = mm + g·tap_v + (1-g)·tap_t
-//                      state_z = Wu_z·act(Wd_z·F_z + bd_z) + bu_z + F_z                      (three towers z)
-//   E_z = head_z(fc_z(state_z))                                            -> item3 = [E_cv | E_text | E_mm]
+//   aligned step i (cv block kc = i + diff_cv, text block kt = i + diff_t, mm block i):
+//       F_cv = g·tap_v[kc] + (1-g)·cv      F_t = g·tap_t[kt] + (1-g)·text      F_mm = mm + g·a_v + (1-g)·a_t
+//       state_z = Wu_z·act(Wd_z·F_z + bd_z) + bu_z + F_z                 (a_v / a_t = tap or its dim-aligned projection)
+//   E_z = head_z(fc_z(state_z))                                          -> item3 = [E_cv | E_text | E_mm]
 //
-// All fp32.  The three towers have identical shapes, so every GEMM / column-sum / fusion step is ONE launch with
-// three problems.  Fusion kernels are HBM-bound (16-byte lanes, taps read in place from the [M, L, D] tap tensor);
-// GEMMs run on the f32 matrix cores (gemm32.hip).  Saved for backward: F, pre-activation U, activation, state per
-// step (the [M,64] bottlenecks are tiny; F/state are 2·n·3·M·D floats).
+// All fp32.  Every GEMM / column-sum / fusion step of the (up to) three towers is ONE launch with several problems
+// (per-problem shapes, so Versa's 8192-wide text tower and 1024-wide image tower share launches too).  Fusion kernels
+// are HBM-bound (16-byte lanes, taps read in place from the [M, L, D] tap tensor); GEMMs run on the f32 matrix cores
+// (gemm32.hip).  Saved for backward: F, pre-activation U, activation, state per step, the dim-aligned taps.
 #include "common.h"
 
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
@@ -17,143 +22,159 @@ int launch_colsum(const float* const* X, float* const* out, const int64_t* M, co
 
 namespace {
 
+// one tower of one fusion step.  type 0: F = g·a + (1-g)·prev ; type 1: F = prev + g·a + (1-g)·b  (not gated: plain sums)
+struct FuseTower {
+    const float* a; const float* b; const float* prev;      // row r at a + r*lda (floats); prev null = zeros
+    int64_t lda, ldb, ldp;
+    const float* gate;                                       // device scalar theta, null = not gated
+    float* F;                                                // fwd: output [M,D] ; bwd: dF in, dprev out (in place)
+    float* da; float* db;                                    // bwd only: optional gradients wrt a / b ([M,D])
+    float* dgate;                                            // bwd only: accumulates d theta
+    int32_t D, type;
+};
 struct FuseArgs {
-    const float* taps_cv; const float* taps_text;     // [M, stride, D]
-    int64_t M; int32_t D; int32_t stride_cv, stride_text, idx;
-    const float* gate[3];      // device scalars (theta) or null when not gated
-    const float* prev[3];      // previous state [M, D] or null (= zeros)
-    int32_t prev_is_tap;       // remove_first, k == 0: prev_cv / prev_text are taps[:, first_index]
-    int32_t first_index;
-    float* F[3];               // outputs
+    FuseTower t[3];
+    int64_t M;
 };
 
 __device__ __forceinline__ float gate_of(const float* theta) { return 1.0f / (1.0f + __expf(-theta[0] / 0.1f)); }
 
-__global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a) {
-    const int z = blockIdx.y;
-    const int d4 = a.D / 4;
-    const int64_t total = a.M * d4;
-    const bool gated = a.gate[0] != nullptr;
-    const float g = gated ? gate_of(a.gate[z]) : 1.0f;
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs args) {
+    const FuseTower& t = args.t[blockIdx.y];
+    const int d4 = t.D / 4;
+    const int64_t total = args.M * d4;
+    const bool gated = t.gate != nullptr;
+    const float g = gated ? gate_of(t.gate) : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / d4;
         const int c = (int)(i - m * d4) * 4;
-        const f4 tv = *(const f4*)(a.taps_cv + (m * a.stride_cv + a.idx) * a.D + c);
-        const f4 tt = *(const f4*)(a.taps_text + (m * a.stride_text + a.idx) * a.D + c);
-        f4 pv = {0.f, 0.f, 0.f, 0.f};
-        if (a.prev[z]) pv = *(const f4*)(a.prev[z] + m * a.D + c);
-        else if (a.prev_is_tap && z == 0) pv = *(const f4*)(a.taps_cv + (m * a.stride_cv + a.first_index) * a.D + c);
-        else if (a.prev_is_tap && z == 1) pv = *(const f4*)(a.taps_text + (m * a.stride_text + a.first_index) * a.D + c);
+        const f4 av = *(const f4*)(t.a + m * t.lda + c);
+        f4 pv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+        if (t.prev) pv = *(const f4*)(t.prev + m * t.ldp + c);
+        if (t.type == 1) bv = *(const f4*)(t.b + m * t.ldb + c);
         f4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (z == 0) o[e] = gated ? g * tv[e] + (1.f - g) * pv[e] : tv[e] + pv[e];
-            else if (z == 1) o[e] = gated ? g * tt[e] + (1.f - g) * pv[e] : tt[e] + pv[e];
-            else o[e] = gated ? pv[e] + g * tv[e] + (1.f - g) * tt[e] : pv[e] + tv[e] + tt[e];
+            if (t.type == 0) o[e] = gated ? g * av[e] + (1.f - g) * pv[e] : av[e] + pv[e];
+            else o[e] = gated ? pv[e] + g * av[e] + (1.f - g) * bv[e] : pv[e] + av[e] + bv[e];
         }
-        *(f4*)(a.F[z] + m * a.D + c) = o;
+        *(f4*)(t.F + m * t.D + c) = o;
     }
 }
 
-struct FuseBwdArgs {
-    const float* taps_cv; const float* taps_text;
-    int64_t M; int32_t D; int32_t stride_cv, stride_text, idx;
-    const float* gate[3];
-    const float* prev[3];
-    int32_t prev_is_tap, first_index;
-    float* dF[3];              // in: grad wrt F_z ; out (in place): grad wrt prev_z
-    float* dgate[3];           // accumulate d theta
-};
-
-// dprev = (1-g)·dF (cv,text) | dF (mm);  dtheta += [sum dF⊙(tap_a - b)] · g(1-g)/0.1
-__global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseBwdArgs a) {
+// in: dF (in t.F).  out: dprev in place ((1-g)·dF for type 0, dF for type 1), optional da = g·dF, db = (1-g)·dF,
+// dtheta += [sum dF ⊙ (a - prev | a - b)] · g(1-g)/0.1
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs args) {
     __shared__ float red[4];
-    const int z = blockIdx.y;
-    const int d4 = a.D / 4;
-    const int64_t total = a.M * d4;
-    const bool gated = a.gate[0] != nullptr;
-    const float g = gated ? gate_of(a.gate[z]) : 1.0f;
+    const FuseTower& t = args.t[blockIdx.y];
+    const int d4 = t.D / 4;
+    const int64_t total = args.M * d4;
+    const bool gated = t.gate != nullptr;
+    const float g = gated ? gate_of(t.gate) : 1.0f;
     float part = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / d4;
         const int c = (int)(i - m * d4) * 4;
-        float* dp = a.dF[z] + m * a.D + c;
+        float* dp = t.F + m * t.D + c;
         const f4 df = *(const f4*)dp;
-        if (!gated) continue;                      // dprev = dF: already in place
-        const f4 tv = *(const f4*)(a.taps_cv + (m * a.stride_cv + a.idx) * a.D + c);
-        const f4 tt = *(const f4*)(a.taps_text + (m * a.stride_text + a.idx) * a.D + c);
-        f4 pv = {0.f, 0.f, 0.f, 0.f};
-        if (a.prev[z]) pv = *(const f4*)(a.prev[z] + m * a.D + c);
-        else if (a.prev_is_tap && z == 0) pv = *(const f4*)(a.taps_cv + (m * a.stride_cv + a.first_index) * a.D + c);
-        else if (a.prev_is_tap && z == 1) pv = *(const f4*)(a.taps_text + (m * a.stride_text + a.first_index) * a.D + c);
-        f4 o;
+        if (gated) {
+            const f4 av = *(const f4*)(t.a + m * t.lda + c);
+            f4 ov = {0.f, 0.f, 0.f, 0.f};
+            if (t.type == 1) ov = *(const f4*)(t.b + m * t.ldb + c);
+            else if (t.prev) ov = *(const f4*)(t.prev + m * t.ldp + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (z == 0) { part += df[e] * (tv[e] - pv[e]); o[e] = (1.f - g) * df[e]; }
-            else if (z == 1) { part += df[e] * (tt[e] - pv[e]); o[e] = (1.f - g) * df[e]; }
-            else { part += df[e] * (tv[e] - tt[e]); o[e] = df[e]; }
+            for (int e = 0; e < 4; ++e) part += df[e] * (av[e] - ov[e]);
         }
-        if (z != 2) *(f4*)dp = o;
+        const float ca = gated ? g : 1.f, cb = gated ? 1.f - g : 1.f;
+        if (t.da) *(f4*)(t.da + m * t.D + c) = (f4){ca * df[0], ca * df[1], ca * df[2], ca * df[3]};
+        if (t.db) *(f4*)(t.db + m * t.D + c) = (f4){cb * df[0], cb * df[1], cb * df[2], cb * df[3]};
+        if (t.type == 0 && gated) *(f4*)dp = (f4){cb * df[0], cb * df[1], cb * df[2], cb * df[3]};
     }
     if (!gated) return;
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.dgate[z], (red[0] + red[1] + red[2] + red[3]) * g * (1.f - g) / 0.1f);
+    if (threadIdx.x == 0) atomicAdd(t.dgate, (red[0] + red[1] + red[2] + red[3]) * g * (1.f - g) / 0.1f);
 }
 
-// parameter table indices (see include/iisan_hip.h)
-struct PIdx {
-    int n;
-    int wd(int z, int k) const { return (z * n + k) * 4 + 0; }
-    int bd(int z, int k) const { return (z * n + k) * 4 + 1; }
-    int wu(int z, int k) const { return (z * n + k) * 4 + 2; }
-    int bu(int z, int k) const { return (z * n + k) * 4 + 3; }
-    int gate(int z, int k) const { return 12 * n + z * n + k; }
-    int fc_w(int z) const { return 15 * n + 2 * z; }
-    int fc_b(int z) const { return 15 * n + 2 * z + 1; }
-    int head_w(int z) const { return 15 * n + 6 + 2 * z; }
-    int head_b(int z) const { return 15 * n + 6 + 2 * z + 1; }
+// ---- static description of one configuration -----------------------------------------------------------------
+struct Plan {
+    int n[3];            // SANBs per tower (cv, text, mm)
+    int D[3];            // tower widths
+    int H[3];            // width between fc_z and head_z
+    int r, E;
+    int diff_cv, diff_t; // surplus leading blocks of the longer tower
+    bool align;          // dim-align projections present
+    bool text_wide;      // which tap is projected
+    // parameter table offsets
+    int p_adapter[3], p_gate[3], p_dp, p_fc[3], p_head[3], n_params;
+    int wd(int z, int k) const { return p_adapter[z] + 4 * k; }
+    int gate(int z, int k) const { return p_gate[z] + k; }
+    int dpw(int i) const { return p_dp + 2 * i; }
 };
+
+int make_plan(const iisan_side_cfg* c, Plan& p) {
+    IISAN_CHECK_SHAPE(c->n_side >= 1 && c->n_side <= IISAN_MAX_SIDE, "side_net: n_side %d out of range", c->n_side);
+    const int n_t = c->versa ? c->n_side_text : c->n_side;
+    IISAN_CHECK_SHAPE(n_t >= 1 && n_t <= IISAN_MAX_SIDE, "side_net: n_side_text %d out of range", n_t);
+    IISAN_CHECK_SHAPE(c->dim_cv % 4 == 0 && c->dim_text % 4 == 0 && c->down % 4 == 0 && c->emb % 4 == 0,
+                      "side_net: widths must be multiples of 4");
+    IISAN_CHECK_SHAPE(c->versa || c->dim_cv == c->dim_text, "side_net: towers of different width (%d vs %d) need versa = 1 "
+                      "(Code_Cached_Asym)", c->dim_cv, c->dim_text);
+    p.n[0] = c->n_side; p.n[1] = n_t; p.n[2] = p.n[0] < p.n[1] ? p.n[0] : p.n[1];
+    p.D[0] = c->dim_cv; p.D[1] = c->dim_text; p.D[2] = c->dim_cv < c->dim_text ? c->dim_cv : c->dim_text;
+    p.r = c->down; p.E = c->emb;
+    p.diff_cv = p.n[0] > p.n[1] ? p.n[0] - p.n[1] : 0;
+    p.diff_t = p.n[1] > p.n[0] ? p.n[1] - p.n[0] : 0;
+    p.align = c->versa && c->dim_cv != c->dim_text;
+    p.text_wide = c->dim_text > c->dim_cv;
+    if (c->versa) { p.H[0] = p.E; p.H[1] = p.E; p.H[2] = p.D[2]; }
+    else { p.H[0] = p.D[0]; p.H[1] = p.D[1]; p.H[2] = p.D[2]; }
+    int o = 0;
+    for (int z = 0; z < 3; ++z) { p.p_adapter[z] = o; o += 4 * p.n[z]; }
+    for (int z = 0; z < 3; ++z) { p.p_gate[z] = o; o += p.n[z]; }
+    p.p_dp = o; if (p.align) o += 2 * p.n[2];
+    for (int z = 0; z < 3; ++z) { p.p_fc[z] = o; o += 2; }
+    for (int z = 0; z < 3; ++z) { p.p_head[z] = o; o += 2; }
+    p.n_params = o;
+    for (int k = 0; k < p.n[0]; ++k)
+        IISAN_CHECK_SHAPE(c->tap_index[k] >= 0 && c->tap_index[k] < c->tap_stride_cv, "side_net: cv tap index %d outside the tap tensor", c->tap_index[k]);
+    for (int k = 0; k < p.n[1]; ++k) {
+        const int ti = c->versa ? c->tap_index_text[k] : c->tap_index[k];
+        IISAN_CHECK_SHAPE(ti >= 0 && ti < c->tap_stride_text, "side_net: text tap index %d outside the tap tensor", ti);
+    }
+    return IISAN_OK;
+}
 
 struct SideBufs {
     float* F[IISAN_MAX_SIDE][3];
     float* U[IISAN_MAX_SIDE][3];
     float* A[IISAN_MAX_SIDE][3];     // activation(U)
     float* O[IISAN_MAX_SIDE][3];     // state after SANB k
+    float* DP[IISAN_MAX_SIDE];       // dim-aligned taps [M, d]
     float* Y[3];                     // fc_z(state)
-    float* dO[3];                    // backward scratch [M, D]
-    float* dY[3];
+    float* dO[3];                    // backward scratch [M, D_z]
+    float* dY[3];                    // [M, H_z]
     float* dU[3];                    // [M, down]
+    float* dDP;                      // [M, d]
 };
 
-void carve(WsCarver& c, SideBufs& b, const iisan_side_cfg* cfg, int64_t M) {
-    const size_t MD = (size_t)M * cfg->dim_cv, Mr = (size_t)M * cfg->down;
-    for (int k = 0; k < cfg->n_side; ++k)
-        for (int z = 0; z < 3; ++z) {
-            b.F[k][z] = c.take<float>(MD);
-            b.U[k][z] = c.take<float>(Mr);
-            b.A[k][z] = c.take<float>(Mr);
-            b.O[k][z] = c.take<float>(MD);
+void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
+    for (int z = 0; z < 3; ++z)
+        for (int k = 0; k < p.n[z]; ++k) {
+            b.F[k][z] = c.take<float>((size_t)M * p.D[z]);
+            b.U[k][z] = c.take<float>((size_t)M * p.r);
+            b.A[k][z] = c.take<float>((size_t)M * p.r);
+            b.O[k][z] = c.take<float>((size_t)M * p.D[z]);
         }
+    for (int i = 0; i < p.n[2]; ++i) b.DP[i] = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
     for (int z = 0; z < 3; ++z) {
-        b.Y[z] = c.take<float>(MD);
-        b.dO[z] = c.take<float>(MD);
-        b.dY[z] = c.take<float>(MD);
-        b.dU[z] = c.take<float>(Mr);
+        b.Y[z] = c.take<float>((size_t)M * p.H[z]);
+        b.dO[z] = c.take<float>((size_t)M * p.D[z]);
+        b.dY[z] = c.take<float>((size_t)M * p.H[z]);
+        b.dU[z] = c.take<float>((size_t)M * p.r);
     }
-}
-
-int check_cfg(const iisan_side_cfg* cfg, int64_t M) {
-    IISAN_CHECK_SHAPE(M > 0, "side_net: M must be positive");
-    IISAN_CHECK_SHAPE(cfg->n_side >= 1 && cfg->n_side <= IISAN_MAX_SIDE, "side_net: n_side %d out of range", cfg->n_side);
-    IISAN_CHECK_SHAPE(cfg->dim_cv == cfg->dim_text, "side_net: towers of different width (%d vs %d) are the Versa variant "
-                      "(Code_Cached_Asym), not built yet", cfg->dim_cv, cfg->dim_text);
-    IISAN_CHECK_SHAPE(cfg->dim_cv % 4 == 0 && cfg->down % 4 == 0 && cfg->emb % 4 == 0, "side_net: widths must be multiples of 4");
-    for (int k = 0; k < cfg->n_side; ++k)
-        IISAN_CHECK_SHAPE(cfg->tap_index[k] >= 0 && cfg->tap_index[k] < cfg->tap_stride_cv && cfg->tap_index[k] < cfg->tap_stride_text,
-                          "side_net: tap index %d outside the tap tensor", cfg->tap_index[k]);
-    return IISAN_OK;
+    b.dDP = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
 }
 
 Gemm32Prob prob(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int64_t M, int N,
@@ -169,55 +190,131 @@ unsigned ew_grid(int64_t M, int D) {
     return (unsigned)(b < 4096 ? b : 4096);
 }
 
+// which towers take part in global step g (0 .. diff + n_mm - 1) and with which block index
+struct StepMap {
+    int nact; int z[3]; int k[3]; int mm_i;     // mm_i = -1 when the step is a surplus (single-tower) step
+};
+StepMap step_map(const Plan& p, int g) {
+    StepMap s{};
+    const int diff = p.diff_cv + p.diff_t;
+    if (g < diff) {
+        s.nact = 1; s.z[0] = p.diff_cv ? 0 : 1; s.k[0] = g; s.mm_i = -1;
+    } else {
+        const int i = g - diff;
+        s.nact = 3; s.mm_i = i;
+        s.z[0] = 0; s.k[0] = i + p.diff_cv;
+        s.z[1] = 1; s.k[1] = i + p.diff_t;
+        s.z[2] = 2; s.k[2] = i;
+    }
+    return s;
+}
+
+struct Ctx {
+    const iisan_side_cfg* cfg; Plan p; SideBufs b;
+    const float* taps[2]; int64_t M;
+    const void* const* params;
+    const float* W(int i) const { return (const float*)params[i]; }
+    int tap_idx(int z, int k) const { return (z == 1 && cfg->versa) ? cfg->tap_index_text[k] : cfg->tap_index[k]; }
+    int64_t tap_ld(int z) const { return (int64_t)(z == 0 ? cfg->tap_stride_cv : cfg->tap_stride_text) * p.D[z]; }
+    const float* tap(int z, int k) const { return taps[z] + (int64_t)tap_idx(z, k) * p.D[z]; }
+    int first_idx(int z) const { return (z == 1 && cfg->versa) ? cfg->first_index_text : cfg->first_index; }
+    // fusion operands of tower z at its block k (mm: k = i)
+    void fuse_operands(FuseTower& t, int z, int k, const StepMap& sm) const {
+        t.D = p.D[z];
+        t.gate = cfg->gated ? W(p.gate(z, k)) : nullptr;
+        t.prev = nullptr; t.ldp = p.D[z];
+        if (k > 0) t.prev = b.O[k - 1][z];
+        else if (cfg->remove_first && z != 2) { t.prev = taps[z] + (int64_t)first_idx(z) * p.D[z]; t.ldp = tap_ld(z); }
+        if (z != 2) {
+            t.type = 0; t.a = tap(z, k); t.lda = tap_ld(z); t.b = nullptr; t.ldb = 0;
+        } else {
+            t.type = 1;
+            const int kc = sm.k[0], kt = sm.k[1];
+            t.a = tap(0, kc); t.lda = tap_ld(0);
+            t.b = tap(1, kt); t.ldb = tap_ld(1);
+            if (p.align) {
+                if (p.text_wide) { t.b = b.DP[k]; t.ldb = p.D[2]; }
+                else { t.a = b.DP[k]; t.lda = p.D[2]; }
+            }
+        }
+    }
+};
+
+int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
+          const void* const* params, void* ws, size_t ws_bytes, const char* who) {
+    IISAN_CHECK_SHAPE(M > 0, "side_net: M must be positive");
+    c.cfg = cfg;
+    IISAN_TRY(make_plan(cfg, c.p));
+    WsCarver w(ws, ws_bytes);
+    carve(w, c.b, c.p, M);
+    if (w.overflow || !ws) {
+        iisan_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, w.off);
+        return IISAN_EWORKSPACE;
+    }
+    c.taps[0] = taps_cv; c.taps[1] = taps_text; c.M = M; c.params = params;
+    return IISAN_OK;
+}
+
 }  // namespace
 
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {
+    Plan p;
+    if (make_plan(cfg, p) != IISAN_OK) return 0;
     WsCarver c(nullptr, 0);
     SideBufs b;
-    carve(c, b, cfg, M);
+    carve(c, b, p, M);
     return c.off;
+}
+
+extern "C" int32_t iisan_side_net_num_params(const iisan_side_cfg* cfg) {
+    Plan p;
+    if (make_plan(cfg, p) != IISAN_OK) return -1;
+    return p.n_params;
 }
 
 extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
                                   const void* const* params, float* item3, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    IISAN_TRY(check_cfg(cfg, M));
-    WsCarver c(ws, ws_bytes);
-    SideBufs b;
-    carve(c, b, cfg, M);
-    if (c.overflow || !ws) {
-        iisan_set_error("side_net_fwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
-        return IISAN_EWORKSPACE;
-    }
-    const int n = cfg->n_side, D = cfg->dim_cv, r = cfg->down, E = cfg->emb;
-    const PIdx P{n};
-    auto W = [&](int i) { return (const float*)params[i]; };
+    Ctx c;
+    IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_fwd"));
+    const Plan& p = c.p;
+    SideBufs& b = c.b;
     const int act_flag = cfg->gelu ? G32_GELU : G32_RELU;
-    for (int k = 0; k < n; ++k) {
-        FuseArgs fa{};
-        fa.taps_cv = taps_cv; fa.taps_text = taps_text; fa.M = M; fa.D = D;
-        fa.stride_cv = cfg->tap_stride_cv; fa.stride_text = cfg->tap_stride_text; fa.idx = cfg->tap_index[k];
-        fa.prev_is_tap = (k == 0 && cfg->remove_first) ? 1 : 0;
-        fa.first_index = cfg->first_index;
-        for (int z = 0; z < 3; ++z) {
-            fa.gate[z] = cfg->gated ? W(P.gate(z, k)) : nullptr;
-            fa.prev[z] = k > 0 ? b.O[k - 1][z] : nullptr;
-            fa.F[z] = b.F[k][z];
+    const int nsteps = p.diff_cv + p.diff_t + p.n[2];
+    for (int g = 0; g < nsteps; ++g) {
+        const StepMap sm = step_map(p, g);
+        if (sm.mm_i >= 0 && p.align) {        // dim-align the wider modality's tap (Code_Cached_Asym/model/model.py:404-411)
+            const int zw = p.text_wide ? 1 : 0;
+            Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
+                                 b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
+            IISAN_TRY(launch_gemm32(&pd, 1, 0, s));
         }
-        hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid(M, D), 3), dim3(256), 0, s, fa);
+        FuseArgs fa{};
+        fa.M = M;
+        int maxD = 0;
+        for (int a = 0; a < sm.nact; ++a) {
+            c.fuse_operands(fa.t[a], sm.z[a], sm.k[a], sm);
+            fa.t[a].F = b.F[sm.k[a]][sm.z[a]];
+            if (p.D[sm.z[a]] > maxD) maxD = p.D[sm.z[a]];
+        }
+        hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid(M, maxD), sm.nact), dim3(256), 0, s, fa);
         IISAN_LAUNCH_OK();
         Gemm32Prob pr[3];
-        for (int z = 0; z < 3; ++z)   // U = F Wd^T + bd (saved), A = act(U)
-            pr[z] = prob(b.F[k][z], D, W(P.wd(z, k)), D, W(P.bd(z, k)), b.A[k][z], r, M, r, D, nullptr, 0, b.U[k][z]);
-        IISAN_TRY(launch_gemm32(pr, 3, act_flag | G32_PREACT, s));
-        for (int z = 0; z < 3; ++z)   // state = A Wu^T + bu + F
-            pr[z] = prob(b.A[k][z], r, W(P.wu(z, k)), r, W(P.bu(z, k)), b.O[k][z], D, M, D, r, b.F[k][z], D);
-        IISAN_TRY(launch_gemm32(pr, 3, 0, s));
+        for (int a = 0; a < sm.nact; ++a) {   // U = F Wd^T + bd (saved), A = act(U)
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.F[k][z], p.D[z], c.W(p.wd(z, k)), p.D[z], c.W(p.wd(z, k) + 1), b.A[k][z], p.r, M, p.r, p.D[z], nullptr, 0, b.U[k][z]);
+        }
+        IISAN_TRY(launch_gemm32(pr, sm.nact, act_flag | G32_PREACT, s));
+        for (int a = 0; a < sm.nact; ++a) {   // state = A Wu^T + bu + F
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.A[k][z], p.r, c.W(p.wd(z, k) + 2), p.r, c.W(p.wd(z, k) + 3), b.O[k][z], p.D[z], M, p.D[z], p.r, b.F[k][z], p.D[z]);
+        }
+        IISAN_TRY(launch_gemm32(pr, sm.nact, 0, s));
     }
     Gemm32Prob pr[3];
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.O[n - 1][z], D, W(P.fc_w(z)), D, W(P.fc_b(z)), b.Y[z], D, M, D, D);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
     IISAN_TRY(launch_gemm32(pr, 3, 0, s));
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.Y[z], D, W(P.head_w(z)), D, W(P.head_b(z)), item3 + z * E, 3 * E, M, E, D);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(b.Y[z], p.H[z], c.W(p.p_head[z]), p.H[z], c.W(p.p_head[z] + 1), item3 + z * p.E, 3 * p.E, M, p.E, p.H[z]);
     IISAN_TRY(launch_gemm32(pr, 3, 0, s));
     return IISAN_OK;
 }
@@ -226,65 +323,86 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
                                   const void* const* params, const float* d_item3, void* const* grads, void* ws,
                                   size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    IISAN_TRY(check_cfg(cfg, M));
-    WsCarver c(ws, ws_bytes);
-    SideBufs b;
-    carve(c, b, cfg, M);
-    if (c.overflow || !ws) {
-        iisan_set_error("side_net_bwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
-        return IISAN_EWORKSPACE;
-    }
-    const int n = cfg->n_side, D = cfg->dim_cv, r = cfg->down, E = cfg->emb;
-    const PIdx P{n};
-    auto W = [&](int i) { return (const float*)params[i]; };
+    Ctx c;
+    IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_bwd"));
+    const Plan& p = c.p;
+    SideBufs& b = c.b;
+    const int E = p.E, r = p.r;
     auto G = [&](int i) { return (float*)grads[i]; };
     Gemm32Prob pr[3];
     const float* cs_x[3]; float* cs_o[3]; int64_t cs_m[3] = {M, M, M}; int32_t cs_n[3], cs_ld[3];
 
     // heads: E_z = Y_z Wh^T + bh
-    for (int z = 0; z < 3; ++z) pr[z] = prob(d_item3 + z * E, 3 * E, W(P.head_w(z)), D, nullptr, b.dY[z], D, M, D, E);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(d_item3 + z * E, 3 * E, c.W(p.p_head[z]), p.H[z], nullptr, b.dY[z], p.H[z], M, p.H[z], E);
     IISAN_TRY(launch_gemm32(pr, 3, G32_TB, s));                                   // dY = dE · Wh
-    for (int z = 0; z < 3; ++z) pr[z] = prob(d_item3 + z * E, 3 * E, b.Y[z], D, nullptr, G(P.head_w(z)), D, E, D, M);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(d_item3 + z * E, 3 * E, b.Y[z], p.H[z], nullptr, G(p.p_head[z]), p.H[z], E, p.H[z], M);
     IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));              // dWh += dE^T · Y
-    for (int z = 0; z < 3; ++z) { cs_x[z] = d_item3 + z * E; cs_o[z] = G(P.head_b(z)); cs_n[z] = E; cs_ld[z] = 3 * E; }
+    for (int z = 0; z < 3; ++z) { cs_x[z] = d_item3 + z * E; cs_o[z] = G(p.p_head[z] + 1); cs_n[z] = E; cs_ld[z] = 3 * E; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
     // fc: Y_z = O_z Wf^T + bf
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], D, W(P.fc_w(z)), D, nullptr, b.dO[z], D, M, D, D);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], c.W(p.p_fc[z]), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], p.H[z]);
     IISAN_TRY(launch_gemm32(pr, 3, G32_TB, s));                                   // dO = dY · Wf
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], D, b.O[n - 1][z], D, nullptr, G(P.fc_w(z)), D, D, D, M);
+    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], b.O[p.n[z] - 1][z], p.D[z], nullptr, G(p.p_fc[z]), p.D[z], p.H[z], p.D[z], M);
     IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));              // dWf += dY^T · O
-    for (int z = 0; z < 3; ++z) { cs_x[z] = b.dY[z]; cs_o[z] = G(P.fc_b(z)); cs_n[z] = D; cs_ld[z] = D; }
+    for (int z = 0; z < 3; ++z) { cs_x[z] = b.dY[z]; cs_o[z] = G(p.p_fc[z] + 1); cs_n[z] = p.H[z]; cs_ld[z] = p.H[z]; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
 
-    for (int k = n - 1; k >= 0; --k) {
+    const int nsteps = p.diff_cv + p.diff_t + p.n[2];
+    for (int g = nsteps - 1; g >= 0; --g) {
+        const StepMap sm = step_map(p, g);
+        const int na = sm.nact;
         // state = A Wu^T + bu + F ; A = act(U) ; U = F Wd^T + bd
-        for (int z = 0; z < 3; ++z)
-            pr[z] = prob(b.dO[z], D, W(P.wu(z, k)), r, nullptr, b.dU[z], r, M, r, D, nullptr, 0, b.U[k][z]);
-        IISAN_TRY(launch_gemm32(pr, 3, G32_TB | (cfg->gelu ? G32_MUL_GELU_GRAD : G32_MUL_RELU_MASK), s));  // dU
-        for (int z = 0; z < 3; ++z) pr[z] = prob(b.dO[z], D, b.A[k][z], r, nullptr, G(P.wu(z, k)), r, D, r, M);
-        IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));          // dWu += dO^T · A
-        for (int z = 0; z < 3; ++z) { cs_x[z] = b.dO[z]; cs_o[z] = G(P.bu(z, k)); cs_n[z] = D; cs_ld[z] = D; }
-        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
-        for (int z = 0; z < 3; ++z) pr[z] = prob(b.dU[z], r, b.F[k][z], D, nullptr, G(P.wd(z, k)), D, r, D, M);
-        IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));          // dWd += dU^T · F
-        for (int z = 0; z < 3; ++z) { cs_x[z] = b.dU[z]; cs_o[z] = G(P.bd(z, k)); cs_n[z] = r; cs_ld[z] = r; }
-        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
-        for (int z = 0; z < 3; ++z) pr[z] = prob(b.dU[z], r, W(P.wd(z, k)), D, nullptr, b.dO[z], D, M, D, r, b.dO[z], D);
-        IISAN_TRY(launch_gemm32(pr, 3, G32_TB, s));                               // dF = dO + dU · Wd (in place)
-        if (cfg->gated) {
-            FuseBwdArgs fa{};
-            fa.taps_cv = taps_cv; fa.taps_text = taps_text; fa.M = M; fa.D = D;
-            fa.stride_cv = cfg->tap_stride_cv; fa.stride_text = cfg->tap_stride_text; fa.idx = cfg->tap_index[k];
-            fa.prev_is_tap = (k == 0 && cfg->remove_first) ? 1 : 0;
-            fa.first_index = cfg->first_index;
-            for (int z = 0; z < 3; ++z) {
-                fa.gate[z] = W(P.gate(z, k));
-                fa.prev[z] = k > 0 ? b.O[k - 1][z] : nullptr;
-                fa.dF[z] = b.dO[z];
-                fa.dgate[z] = G(P.gate(z, k));
+        for (int a = 0; a < na; ++a) {
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.dO[z], p.D[z], c.W(p.wd(z, k) + 2), r, nullptr, b.dU[z], r, M, r, p.D[z], nullptr, 0, b.U[k][z]);
+        }
+        IISAN_TRY(launch_gemm32(pr, na, G32_TB | (cfg->gelu ? G32_MUL_GELU_GRAD : G32_MUL_RELU_MASK), s));  // dU
+        for (int a = 0; a < na; ++a) {
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);
+        }
+        IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWu += dO^T · A
+        for (int a = 0; a < na; ++a) { const int z = sm.z[a], k = sm.k[a]; cs_x[a] = b.dO[z]; cs_o[a] = G(p.wd(z, k) + 3); cs_n[a] = p.D[z]; cs_ld[a] = p.D[z]; }
+        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, na, s));
+        for (int a = 0; a < na; ++a) {
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.dU[z], r, b.F[k][z], p.D[z], nullptr, G(p.wd(z, k)), p.D[z], r, p.D[z], M);
+        }
+        IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWd += dU^T · F
+        for (int a = 0; a < na; ++a) { const int z = sm.z[a], k = sm.k[a]; cs_x[a] = b.dU[z]; cs_o[a] = G(p.wd(z, k) + 1); cs_n[a] = r; cs_ld[a] = r; }
+        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, na, s));
+        for (int a = 0; a < na; ++a) {
+            const int z = sm.z[a], k = sm.k[a];
+            pr[a] = prob(b.dU[z], r, c.W(p.wd(z, k)), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], r, b.dO[z], p.D[z]);
+        }
+        IISAN_TRY(launch_gemm32(pr, na, G32_TB, s));                              // dF = dO + dU · Wd (in place)
+
+        const bool need_dp = sm.mm_i >= 0 && p.align;
+        if (cfg->gated || need_dp) {
+            FuseArgs fa{};
+            fa.M = M;
+            int maxD = 0;
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                c.fuse_operands(fa.t[a], z, k, sm);
+                fa.t[a].F = b.dO[z];
+                fa.t[a].dgate = cfg->gated ? G(p.gate(z, k)) : nullptr;
+                fa.t[a].da = nullptr; fa.t[a].db = nullptr;
+                if (z == 2 && need_dp) { if (p.text_wide) fa.t[a].db = b.dDP; else fa.t[a].da = b.dDP; }
+                if (p.D[z] > maxD) maxD = p.D[z];
             }
-            hipLaunchKernelGGL(fuse_bwd_kernel, dim3(ew_grid(M, D), 3), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(fuse_bwd_kernel, dim3(ew_grid(M, maxD), na), dim3(256), 0, s, fa);
             IISAN_LAUNCH_OK();
+        }
+        if (need_dp) {                        // DP = tap_wide · Pd^T + bd
+            const int zw = p.text_wide ? 1 : 0, i = sm.mm_i;
+            Gemm32Prob pd = prob(b.dDP, p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
+            IISAN_TRY(launch_gemm32(&pd, 1, G32_TA | G32_TB | G32_ACCUM, s));     // dPd += dDP^T · tap
+            const float* X[1] = {b.dDP};
+            float* O[1] = {G(p.dpw(i) + 1)};
+            int64_t Ms[1] = {M};
+            int32_t Ns[1] = {p.D[2]}, lds[1] = {p.D[2]};
+            IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, 1, s));
         }
         // not gated: dprev_z = dF_z, already in dO
     }

@@ -3,3 +3,4 @@ constructor signatures, forward signatures and state-dict keys, with the arithme
 from .model import *          # noqa: F401,F403
 from .encoders import *       # noqa: F401,F403
 from .modules import *        # noqa: F401,F403
+from .versa import *          # noqa: F401,F403

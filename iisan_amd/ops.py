@@ -78,6 +78,43 @@ def make_side_cfg(n_side: int, dim: int, down: int, emb: int, gated: bool, gelu:
     return cfg
 
 
+def make_versa_cfg(dim_cv: int, dim_text: int, down: int, emb: int, gated: bool, gelu: bool, remove_first: bool,
+                   tap_stride_cv: int, tap_stride_text: int, tap_index_cv: Sequence[int], tap_index_text: Sequence[int]):
+    """Asymmetric towers (Code_Cached_Asym): separate depth/width/tap lists per modality."""
+    cfg = _lib.SideCfg()
+    cfg.versa = 1
+    cfg.n_side, cfg.n_side_text = len(tap_index_cv), len(tap_index_text)
+    cfg.dim_cv, cfg.dim_text, cfg.down, cfg.emb = dim_cv, dim_text, down, emb
+    cfg.gated, cfg.gelu, cfg.remove_first = int(gated), int(gelu), int(remove_first)
+    cfg.tap_stride_cv, cfg.tap_stride_text = tap_stride_cv, tap_stride_text
+    for k, i in enumerate(tap_index_cv):
+        cfg.tap_index[k] = i
+    for k, i in enumerate(tap_index_text):
+        cfg.tap_index_text[k] = i
+    return cfg
+
+
+def versa_param_order(n_cv: int, n_text: int, align: bool) -> List[str]:
+    """State-dict keys of the Versa wrapper in ABI order (include/iisan_hip.h).  Only the first min(n_cv, n_text)
+    mm adapters / gates / down-projects are ever used by the reference forward (model.py:381-417)."""
+    n_mm = min(n_cv, n_text)
+    names = []
+    for tower, n in (("cv", n_cv), ("bert", n_text), ("mm", n_mm)):
+        for k in range(n):
+            p = f"{tower}_adapter_list.{k}."
+            names += [p + "fc_down.weight", p + "fc_down.bias", p + "fc_up.weight", p + "fc_up.bias"]
+    names += [f"side_gate_params_cv.{k}" for k in range(n_cv)]
+    names += [f"side_gate_params_text.{k}" for k in range(n_text)]
+    names += [f"side_gate_params_mm.{k}" for k in range(n_mm)]
+    if align:
+        for i in range(n_mm):
+            names += [f"down_project_list.{i}.weight", f"down_project_list.{i}.bias"]
+    names += ["fc_cv.weight", "fc_cv.bias", "fc_bert.weight", "fc_bert.bias", "fc_mm.weight", "fc_mm.bias",
+              "cv_pre_fc.weight", "cv_pre_fc.bias", "bert_pre_fc.weight", "bert_pre_fc.bias",
+              "fc_mm_down.weight", "fc_mm_down.bias"]
+    return names
+
+
 class SideNetFn(torch.autograd.Function):
     """(taps_cv [M,Lc,D], taps_text [M,Lt,D], *params) -> item3 [M, 3*emb] = cat[cv, text, mm]."""
 
@@ -88,6 +125,10 @@ class SideNetFn(torch.autograd.Function):
         taps_cv, taps_text = _f32c(taps_cv), _f32c(taps_text)
         params = [_f32c(p.detach()) for p in params]
         M = taps_cv.shape[0]
+        need = lib.iisan_side_net_num_params(C.byref(cfg))
+        if need != len(params):
+            raise _lib.IisanHipError(f"side network expects {need} parameter tensors, got {len(params)}: "
+                                     f"{lib.iisan_last_error().decode()}")
         item3 = torch.empty((M, 3 * cfg.emb), dtype=torch.float32, device=taps_cv.device)
         ws = torch.empty(lib.iisan_side_net_ws_bytes(C.byref(cfg), M), dtype=torch.uint8, device=taps_cv.device)
         tab = _ptr_table(params)

@@ -18,12 +18,15 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .model import CachedIISANAdaptedMModel, IISANAdaptedMModel
+from .model import CachedIISANAdaptedMModel, IISANAdaptedMModel, VersaIISANAdaptedMModel
 
 GROUP_ORDER = ("text_encoder", "image_net", "recsys", "adapter_cv", "adapter_text")     # optimizer order, run.py:330-336
 
 
 def add_interIISAN_adapter_to_model(mm_model, args, cached: bool = False):
+    """`cached`: False = Code_Uncached, True = Code_Cached, "versa" = Code_Cached_Asym."""
+    if cached == "versa":
+        return VersaIISANAdaptedMModel(mm_model, args)
     return (CachedIISANAdaptedMModel if cached else IISANAdaptedMModel)(mm_model, args)
 
 

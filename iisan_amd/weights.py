@@ -345,3 +345,26 @@ def make_trainable_params(seed: int = 99, **shape_kw) -> Dict[str, torch.Tensor]
             t = _normal(rs, shape, math.sqrt(2.0 / (fan_in + fan_out)))
         out[name] = t
     return out
+
+
+def fill_params_seeded(named_shapes: Dict[str, tuple], seed: int) -> Dict[str, torch.Tensor]:
+    """Seeded non-default values for an arbitrary set of named tensors (sorted by name), with the same value rules as
+    `make_trainable_params`.  Used for the Versa fixtures, whose tensor set depends on the depth/width configuration."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name in sorted(named_shapes):
+        shape = tuple(named_shapes[name])
+        if "side_gate_params" in name:
+            t = _normal(rs, shape, 0.08)
+        elif name.endswith("layer_norm.weight"):
+            t = 1.0 + _normal(rs, shape, 0.1)
+        elif name.endswith("bias"):
+            t = _normal(rs, shape, 0.05)
+        elif "adapter_list" in name:
+            t = _normal(rs, shape, 0.05)
+        elif "position_embedding" in name:
+            t = _normal(rs, shape, 0.2)
+        else:
+            t = _normal(rs, shape, math.sqrt(2.0 / (shape[0] + shape[-1])))
+        out[name] = t
+    return out

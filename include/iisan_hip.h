@@ -109,19 +109,33 @@ int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, in
  * the caller zeroes them.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
-    int32_t n_side;           /* number of SANBs per tower (7; 6 with remove_first)                             */
-    int32_t dim_cv, dim_text; /* tap widths (768, 768)                                                          */
+    int32_t n_side;           /* SANBs of the image tower (7; 6 with remove_first); also of the text tower unless versa */
+    int32_t dim_cv, dim_text; /* tap widths (768, 768; Versa e.g. 1024 / 8192)                                  */
     int32_t down;             /* adapter bottleneck (64)                                                        */
     int32_t emb;              /* embedding_dim (64)                                                             */
     int32_t gated;            /* fusion_method == "gated"                                                       */
     int32_t gelu;             /* adapter_activation == "GELU"                                                   */
-    int32_t remove_first;     /* args.remove_first == "TRUE": states start at taps[:,0] (model.py:215-218)      */
+    int32_t remove_first;     /* args.remove_first == "TRUE": states start at taps[:,first_index] (model.py:215-218) */
     int32_t tap_stride_cv;    /* taps are [M, tap_stride, D]; tap_index[k] selects the layer of SANB k          */
     int32_t tap_stride_text;
-    int32_t tap_index[IISAN_MAX_SIDE];     /* index along the tap axis used by SANB k                          */
+    int32_t tap_index[IISAN_MAX_SIDE];     /* tap-axis index used by image SANB k (and text SANB k unless versa) */
     int32_t first_index;                   /* tap index that seeds the states when remove_first                */
+    /* ---- Versa (Code_Cached_Asym/model/model.py:257-429); all zero for the Uncached / Cached variants ---- */
+    int32_t versa;            /* 1: asymmetric towers: heads are fc_cv[E,Dc], fc_bert[E,Dt], fc_mm[d,d] then cv_pre_fc[E,E],
+                                 bert_pre_fc[E,E], fc_mm_down[E,d], d = min(Dc,Dt); group layer-drop; dim-align        */
+    int32_t n_side_text;      /* SANBs of the text tower                                                        */
+    int32_t tap_index_text[IISAN_MAX_SIDE];
+    int32_t first_index_text;
 } iisan_side_cfg;
 
+/* Parameter table (host array of device pointers), n_mm = min(n_cv, n_text):
+ *   image SANBs k=0..n_cv-1:  fc_down.weight, fc_down.bias, fc_up.weight, fc_up.bias
+ *   text  SANBs k=0..n_t-1 :  same          mm SANBs i=0..n_mm-1: same
+ *   gates: image[n_cv], text[n_t], mm[n_mm]   (1-element tensors; ignored when gated == 0)
+ *   versa && dim_cv != dim_text: dim-align down_project_list[i].weight, .bias for i=0..n_mm-1
+ *   fc_cv.w,.b   fc_bert.w,.b   fc_mm.w,.b
+ *   head_cv.w,.b (classifier | cv_pre_fc)   head_text.w,.b (title.fc | bert_pre_fc)   fc_mm_down.w,.b          */
+int32_t iisan_side_net_num_params(const iisan_side_cfg* cfg);
 size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M);        /* saved activations + scratch    */
 /* out: item3 fp32 [M, 3*emb] = cat[cv, text, mm] (the com_dense input, model.py:69) */
 int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,

@@ -166,6 +166,57 @@ def side_network(taps_cv: Tensor, taps_text: Tensor, P: Dict[str, Tensor], layer
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# V1  IISAN-Versa side network                     reference: Code_Cached_Asym/model/model.py:322-429
+# ---------------------------------------------------------------------------------------------------------------
+
+def versa_side_network(taps_cv: Tensor, taps_text: Tensor, P: Dict[str, Tensor], layers_cv: Sequence[int],
+                       layers_text: Sequence[int], fusion: str = "gated", activation: str = "RELU",
+                       remove_first: bool = False, pre: str = "mm_encoder.") -> Tuple[Tensor, Tensor, Tensor]:
+    """Asymmetric towers: taps_cv [M, Lc+1, Di], taps_text [M, Lt+1, Dt].  The longer tower first runs its surplus
+    leading SANBs alone (group layer-drop, model.py:353-378); in the aligned loop the wider modality's tap goes through
+    down_project_list[i] (dim-align, model.py:400-411) before the inter-modal gated sum."""
+    Di, Dt = taps_cv.shape[-1], taps_text.shape[-1]
+    M = taps_cv.shape[0]
+    n_cv, n_t = len(layers_cv), len(layers_text)
+    zc, zt, zm = taps_cv.new_zeros(M, Di), taps_text.new_zeros(M, Dt), taps_cv.new_zeros(M, min(Di, Dt))
+    cv, text = (taps_cv[:, 0], taps_text[:, 0]) if remove_first else (zc, zt)
+    mm = zm
+    gated = fusion == "gated"
+    diff_t, diff_cv = max(n_t - n_cv, 0), max(n_cv - n_t, 0)
+
+    def intra(state, tap, gate_name):
+        if gated:
+            g = torch.sigmoid(P[pre + gate_name] / 0.1)
+            return g * tap + (1 - g) * state
+        return tap + state
+
+    for k in range(diff_t):
+        text = adapter_block(intra(text, taps_text[:, layers_text[k]], f"side_gate_params_text.{k}"), P, pre + f"bert_adapter_list.{k}.", activation)
+    for k in range(diff_cv):
+        cv = adapter_block(intra(cv, taps_cv[:, layers_cv[k]], f"side_gate_params_cv.{k}"), P, pre + f"cv_adapter_list.{k}.", activation)
+    for i in range(min(n_cv, n_t)):
+        kc, kt = i + diff_cv, i + diff_t
+        tv, tt = taps_cv[:, layers_cv[kc]], taps_text[:, layers_text[kt]]
+        text = adapter_block(intra(text, tt, f"side_gate_params_text.{kt}"), P, pre + f"bert_adapter_list.{kt}.", activation)
+        cv = adapter_block(intra(cv, tv, f"side_gate_params_cv.{kc}"), P, pre + f"cv_adapter_list.{kc}.", activation)
+        av, at = tv, tt
+        if Dt > Di:
+            at = F.linear(tt, P[pre + f"down_project_list.{i}.weight"], P[pre + f"down_project_list.{i}.bias"])
+        elif Di > Dt:
+            av = F.linear(tv, P[pre + f"down_project_list.{i}.weight"], P[pre + f"down_project_list.{i}.bias"])
+        if gated:
+            g = torch.sigmoid(P[pre + f"side_gate_params_mm.{i}"] / 0.1)
+            mm = mm + g * av + (1 - g) * at
+        else:
+            mm = mm + av + at       # (the reference always gates here, model.py:413-415; plain sum kept for symmetry)
+        mm = adapter_block(mm, P, pre + f"mm_adapter_list.{i}.", activation)
+    text = F.linear(F.linear(text, P[pre + "fc_bert.weight"], P[pre + "fc_bert.bias"]), P[pre + "bert_pre_fc.weight"], P[pre + "bert_pre_fc.bias"])
+    cv = F.linear(F.linear(cv, P[pre + "fc_cv.weight"], P[pre + "fc_cv.bias"]), P[pre + "cv_pre_fc.weight"], P[pre + "cv_pre_fc.bias"])
+    mm = F.linear(F.linear(mm, P[pre + "fc_mm.weight"], P[pre + "fc_mm.bias"]), P[pre + "fc_mm_down.weight"], P[pre + "fc_mm_down.bias"])
+    return cv, text, mm
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # U5  SASRec user encoder                          reference: Code_Uncached/model/encoders.py:60-65, modules.py:6-96
 # ---------------------------------------------------------------------------------------------------------------
 

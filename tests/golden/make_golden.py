@@ -321,7 +321,56 @@ def gen_eval():
     print(f"eval: Hit@10 {hit10:.4f} nDCG@10 {ndcg10:.4f} (ranks min {ranks.min()} max {ranks.max()})")
 
 
-GENS = dict(encoders_full=gen_encoders_full, sidenet_full=gen_sidenet_full, e2e_small=gen_e2e_small, eval=gen_eval)
+VERSA_VARIANTS = {
+    # name: (Di, Dt, image taps, text taps, vit list, bert list, extra args)
+    "text_wide_long": (256, 512, 6, 10, "0,2,4", "1,3,5,7,8", {}),
+    "image_wide_long": (512, 256, 7, 5, "0,1,2,3,5", "1,3", dict(adapter_activation="GELU")),
+    "equal_rmfirst": (256, 256, 5, 5, "0,2,3", "1,2,3", dict(remove_first="TRUE")),
+}
+
+
+def gen_versa():
+    """IISAN-Versa (Code_Cached_Asym): asymmetric towers, group layer-drop, dim-align."""
+    ref = load_ref_pkg("Code_Cached_Asym", "model")
+    from transformers import BertConfig, BertModel
+    out = {}
+    bs, S = 3, 10
+    b = synth.scientific_batch(bs=bs, seed=78, lengths=[5, 11, 3], dup_items=True, res=16, item_num=50)
+    out.update(ids=b.ids.numpy(), log_mask=b.log_mask.numpy(), pop=b.pop_prob.numpy())
+    for vname, (Di, Dt, Lc, Lt, vlist, blist, extra) in VERSA_VARIANTS.items():
+        args = ref_args(text_embedding_dim=Dt, image_embedding_dim=Di, side_adapter_vit_list=vlist, side_adapter_bert_list=blist,
+                        image_layers=Lc - 1, text_layers=Lt - 1, **extra)
+        bc = BertConfig(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=32, vocab_size=16)
+        model = ref.ModelMM(args, 50, True, _FakeNet(), BertModel(bc), b.pop_prob.numpy())
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        model.mm_encoder = ref.IISANAdaptedMModel(model.mm_encoder, args)
+        train_names = {n: tuple(p_.shape) for n, p_ in model.named_parameters()
+                       if n.startswith("mm_encoder.") or n.startswith("user_encoder.") or n.startswith("com_dense.")}
+        P = weights.fill_params_seeded(train_names, seed=555)
+        missing, unexpected = model.load_state_dict(P, strict=False)
+        assert not unexpected, unexpected
+        model.eval()
+        taps_cv = synth.cached_taps(b.ids, Lc - 1, Di, seed=15)
+        taps_tx = synth.cached_taps(b.ids, Lt - 1, Dt, seed=16)
+        for n, p_ in model.named_parameters():
+            p_.requires_grad_(n in P)
+            p_.grad = None
+        with torch.no_grad():
+            cv, (text, mm) = model.mm_encoder(taps_cv, taps_tx)
+        loss = model(b.ids.view(-1), taps_cv.view(bs, S + 1, Lc, Di), taps_tx.view(bs, S + 1, Lt, Dt), b.log_mask, "cpu")
+        loss.backward()
+        grads = {n: (p_.grad.clone() if p_.grad is not None else None) for n, p_ in model.named_parameters() if n in P}
+        pre = vname + "/"
+        out.update({pre + "cv": cv.numpy(), pre + "text": text.numpy(), pre + "mm": mm.numpy(), pre + "loss": loss.detach().numpy(),
+                    pre + "taps_sha": np.array([sha(taps_cv), sha(taps_tx)]),
+                    pre + "names": np.array(sorted(P)), pre + "unused": np.array(sorted(n for n, g in grads.items() if g is None) or [""])})
+        out.update({pre + k: v for k, v in pack_grads({n: g for n, g in grads.items() if g is not None}).items()})
+        print(f"versa[{vname}]: loss {loss.item():.6f}, {len(P)} tensors, {sum(g is None for g in grads.values())} unused")
+    np.savez_compressed(os.path.join(HERE, "versa.npz"), **out)
+
+
+GENS = dict(versa=gen_versa, encoders_full=gen_encoders_full, sidenet_full=gen_sidenet_full, e2e_small=gen_e2e_small, eval=gen_eval)
 
 if __name__ == "__main__":
     import importlib.machinery  # noqa: F401

@@ -78,3 +78,29 @@ def eval_inputs():
     P = weights.make_trainable_params(seed=99, cached=True)
     tables = [torch.from_numpy(z[k]) for k in ("table_cv", "table_text", "table_mm")]
     return z, seqs, tables, P
+
+
+VERSA_VARIANTS = {
+    "text_wide_long": (256, 512, 6, 10, "0,2,4", "1,3,5,7,8", {}),
+    "image_wide_long": (512, 256, 7, 5, "0,1,2,3,5", "1,3", dict(adapter_activation="GELU")),
+    "equal_rmfirst": (256, 256, 5, 5, "0,2,3", "1,2,3", dict(remove_first="TRUE")),
+}
+
+
+def versa_inputs(variant: str, device="cpu"):
+    """Batch, taps, product model (wired like Code_Cached_Asym/run.py:185-190) and seeded parameters of one Versa fixture."""
+    import helpers
+    z = load("versa.npz")
+    Di, Dt, Lc, Lt, vlist, blist, extra = VERSA_VARIANTS[variant]
+    b = synth.scientific_batch(bs=3, seed=78, lengths=[5, 11, 3], dup_items=True, res=16, item_num=50)
+    assert np.array_equal(b.ids.numpy(), z["ids"])
+    taps_cv = synth.cached_taps(b.ids, Lc - 1, Di, seed=15)
+    taps_tx = synth.cached_taps(b.ids, Lt - 1, Dt, seed=16)
+    assert sha(taps_cv) == str(z[variant + "/taps_sha"][0]) and sha(taps_tx) == str(z[variant + "/taps_sha"][1])
+    args = helpers.make_args(text_embedding_dim=Dt, image_embedding_dim=Di, side_adapter_vit_list=vlist,
+                             side_adapter_bert_list=blist, image_layers=Lc - 1, text_layers=Lt - 1, **extra)
+    model = helpers.build_model(args, 50, b.pop_prob, cached="versa", device=device)
+    shapes = {n: tuple(p.shape) for n, p in model.named_parameters() if p.requires_grad}
+    assert sorted(shapes) == [str(x) for x in z[variant + "/names"]], "Versa module tree differs from the reference's"
+    P = weights.fill_params_seeded(shapes, seed=555)
+    return z, b, taps_cv, taps_tx, args, model, P

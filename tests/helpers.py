@@ -25,7 +25,7 @@ def build_model(args, item_num, pop, vit_w=None, vit_cfg=None, bert_w=None, bert
     vit = FrozenVit(vit_w or {}, vit_cfg or weights.VIT_BASE, args.embedding_dim)
     bert = FrozenBert(bert_w or {}, bert_cfg or weights.BERT_BASE)
     model = ModelMM(args, item_num, True, vit, bert, pop)
-    trainer.apply_iisan_freeze_rules(model, args, cached=cached)
+    trainer.apply_iisan_freeze_rules(model, args, cached=cached)      # cached: False | True | "versa"
     return model.to(device)
 
 

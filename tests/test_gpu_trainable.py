@@ -229,3 +229,30 @@ def test_sasrec_dropout_matches_oracle_with_the_same_masks():
     cfg0 = ops.make_sasrec_cfg(S, E, H, L, 0.0, 0)
     y0 = ops.SasrecFn.apply(cfg0, x.cuda(), lm.cuda(), *[t.detach() for t in params])
     _close(y0, O.sasrec(x, lm, P, H, L), 2e-5, 2e-5, "eval forward")
+
+
+@pytest.mark.parametrize("variant", ["text_wide_long", "image_wide_long", "equal_rmfirst"])
+def test_versa_model_matches_reference(variant):
+    """IISAN-Versa (Code_Cached_Asym): asymmetric towers with group layer-drop and dim-align, forward + backward."""
+    z, b, taps_cv, taps_tx, args, model, P = gio.versa_inputs(variant, device="cuda")
+    helpers.load_trainables(model, P)
+    model.eval()
+    bs, S = b.log_mask.shape
+    Lc, Lt = taps_cv.shape[1], taps_tx.shape[1]
+    tc = taps_cv.view(bs, S + 1, Lc, -1).cuda()
+    tt = taps_tx.view(bs, S + 1, Lt, -1).cuda()
+    pre = variant + "/"
+    cv, (text, mm) = model.mm_encoder(tc, tt)
+    _close(cv, z[pre + "cv"], 3e-5, 3e-5, "cv")
+    _close(text, z[pre + "text"], 3e-5, 3e-5, "text")
+    _close(mm, z[pre + "mm"], 3e-5, 3e-5, "mm")
+    loss = model(b.ids.cuda().view(-1), tc, tt, b.log_mask.cuda(), 0)
+    _close(loss, z[pre + "loss"], 3e-5, 0, "loss")
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, n
+            _close(gio.sample_like_golden(p.grad), z[pre + "g/" + n], 6e-4, 3e-7, f"grad {n}")
+    # fp16 taps on disk (GPTQ Llama caches, preprocess_llama-3-70b_micro.py) are upcast like model.py:402
+    cv16, _ = model.mm_encoder(tc.half(), tt.half())
+    assert cv16.dtype == torch.float32 and torch.isfinite(cv16).all()

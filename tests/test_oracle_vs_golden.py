@@ -121,3 +121,25 @@ def test_eval_ranks_match_reference():
     hit, ndcg = O.hit_ndcg(ranks)
     assert abs(float(hit.mean()) - float(z["hit10"])) < 1e-6
     assert abs(float(ndcg.mean()) - float(z["ndcg10"])) < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["text_wide_long", "image_wide_long", "equal_rmfirst"])
+def test_versa_side_network_matches_reference(variant):
+    z, b, taps_cv, taps_tx, args, model, P = gio.versa_inputs(variant)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lc = O.side_layer_list(args.side_adapter_vit_list, args.remove_first == "TRUE")
+    lt = O.side_layer_list(args.side_adapter_bert_list, args.remove_first == "TRUE")
+    cv, text, mm = O.versa_side_network(taps_cv, taps_tx, P, lc, lt, activation=args.adapter_activation,
+                                        remove_first=args.remove_first == "TRUE")
+    pre = variant + "/"
+    _close(cv.detach(), z[pre + "cv"], 2e-5, 2e-5, "cv")
+    _close(text.detach(), z[pre + "text"], 2e-5, 2e-5, "text")
+    _close(mm.detach(), z[pre + "mm"], 2e-5, 2e-5, "mm")
+    bs, S = b.log_mask.shape
+    score = torch.nn.functional.linear(torch.cat([cv, text, mm], 1), P["com_dense.weight"], P["com_dense.bias"])
+    prec = O.sasrec(score.view(bs, S + 1, 64)[:, :-1], b.log_mask, P, 2, 2).reshape(-1, 64)
+    loss = O.inbatch_ce(b.ids, score, prec, b.log_mask, b.pop_prob)
+    _close(loss.detach(), z[pre + "loss"], 2e-5, 0, "loss")
+    loss.backward()
+    for n, p in P.items():
+        _close(gio.sample_like_golden(p.grad), z[pre + "g/" + n], 5e-4, 1e-7, f"grad {n}")
