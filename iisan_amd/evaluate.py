@@ -1,0 +1,103 @@
+"""Batched evaluation and tap caching on the HIP path — the callers on either side of the hot path.
+
+* `evaluate_ranks` / `hit_ndcg`  replace the per-user Python loop of `eval_model` + the full argsort of `metrics_topK`
+  (`Code_Uncached/data_utils/metrics.py:59-67,157-246`): user vectors from SASRec, scores against the whole item table
+  and the target's rank are computed on the device in two launches per user batch; users are sharded contiguously
+  across ranks like `SequentialDistributedSampler` and gathered on ALL ranks (the reference's rank-0-only test eval would
+  deadlock for world_size > 1).
+* `item_table`  replaces `get_MM_item_embeddings` (`metrics.py:69-107`): items are sharded across ranks instead of being
+  encoded redundantly by every rank.
+* `build_tap_cache`  is what `Code_Cached/preprocess_vectors.py:68-112` does with HuggingFace models: the per-layer CLS
+  taps `[N, L+1, 768]` of a catalogue, from the same encoder kernels as the Uncached path.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import dp, ops
+
+
+@torch.no_grad()
+def build_tap_cache(model, images: torch.Tensor, text: torch.Tensor, batch: int = 256) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CLS taps of every hidden state for a catalogue: ([N, Lc+1, 768], [N, Lt+1, 768]) fp32 on the inputs' device."""
+    enc = model.mm_encoder
+    cvs, txs = [], []
+    for i in range(0, images.shape[0], batch):
+        img, txt = images[i:i + batch].contiguous(), text[i:i + batch].contiguous()
+        Lc = enc.cv_encoder.packed(img.device).cfg.layers
+        Lt = enc.bert_encoder.text_encoders["title"].packed(txt.device).cfg.layers
+        cvs.append(enc.cv_encoder.forward_taps(img, range(Lc + 1)))
+        txs.append(enc.bert_encoder.forward_taps(txt, range(Lt + 1)))
+    return torch.cat(cvs), torch.cat(txs)
+
+
+@torch.no_grad()
+def item_table(model, images_or_taps: torch.Tensor, text_or_taps: torch.Tensor, batch: int = 512, rank: int = 0,
+               world: int = 1) -> torch.Tensor:
+    """Item embedding table `com_dense(cat(cv, text, mm))` [N, emb] for items 0..N-1 (row 0 = the padding item)."""
+    N = images_or_taps.shape[0]
+    per = (N + world - 1) // world
+    lo, hi = min(rank * per, N), min((rank + 1) * per, N)
+    rows = []
+    for i in range(lo, hi, batch):
+        j = min(i + batch, hi)
+        item3, _ = model.mm_encoder.forward_item3(images_or_taps[i:j].contiguous(), text_or_taps[i:j].contiguous())
+        rows.append(ops.LinearFn.apply(item3, model.com_dense.weight, model.com_dense.bias))
+    emb = model.com_dense.weight.shape[0]
+    mine = torch.cat(rows) if rows else torch.empty(0, emb, device=images_or_taps.device)
+    if world == 1:
+        return mine
+    pad = torch.zeros(per, emb, device=mine.device)
+    pad[:mine.shape[0]] = mine
+    return dp.gather_concat(pad, per * world)[:N]
+
+
+def _pack_users(seqs: Sequence[Sequence[int]], max_seq_len: int, hist_stride: int):
+    """Left-padded history tokens / masks (BuildMMEvalDataset, dataset.py:183-189), 0-padded history list, targets."""
+    U = len(seqs)
+    tok = torch.zeros(U, max_seq_len, dtype=torch.int64)
+    lm = torch.zeros(U, max_seq_len)
+    hist = torch.zeros(U, hist_stride, dtype=torch.int32)
+    tgt = torch.zeros(U, dtype=torch.int32)
+    for u, seq in enumerate(seqs):
+        t = list(seq[:-1])[-max_seq_len:]
+        tok[u, max_seq_len - len(t):] = torch.tensor(t, dtype=torch.int64)
+        lm[u, max_seq_len - len(t):] = 1
+        tgt[u] = seq[-1]
+    return tok, lm, hist, tgt
+
+
+@torch.no_grad()
+def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[int]], histories: Sequence[Sequence[int]],
+                   max_seq_len: int, batch: int = 1024, rank: int = 0, world: int = 1) -> torch.Tensor:
+    """1-based rank of every user's target (int32 [U], identical on all ranks).  `eval_seqs[u]` = history + target
+    (`eval_seq`), `histories[u]` = items to exclude (`user_history`, metrics.py:204-205)."""
+    U = len(eval_seqs)
+    hs = max(1, max(len(h) for h in histories))
+    idx = dp.sequential_shard(U, rank, world, batch) if world > 1 else list(range(U))
+    tok, lm, hist, tgt = _pack_users([eval_seqs[i] for i in idx], max_seq_len, hs)
+    for r, i in enumerate(idx):
+        h = torch.tensor(list(histories[i]), dtype=torch.int32)
+        hist[r, :h.numel()] = h
+    dev = item_emb.device
+    was_training = model.training
+    model.eval()
+    out = []
+    for i in range(0, len(idx), batch):
+        t, m = tok[i:i + batch].to(dev), lm[i:i + batch].to(dev)
+        x = item_emb[t]                                            # == com_dense(cat(tables[tokens])), metrics.py:214
+        prec = model.user_encoder(x, m, None)[:, -1].contiguous()   # metrics.py:216
+        out.append(ops.score_rank(prec, item_emb, hist[i:i + batch].to(dev), tgt[i:i + batch].to(dev)))
+    model.train(was_training)
+    ranks = torch.cat(out)
+    return dp.gather_concat(ranks, U) if world > 1 else ranks
+
+
+def hit_ndcg(ranks: torch.Tensor, topk: int = 10) -> Tuple[float, float]:
+    """Hit@k and nDCG@k as `metrics_topK` + `eval_concat` report them (metrics.py:50-67)."""
+    r = ranks.to(torch.float64)
+    hit = (r <= topk).to(torch.float64)
+    ndcg = torch.where(r <= topk, 1.0 / torch.log2(r + 1.0), torch.zeros_like(r))
+    return float(hit.mean()), float(ndcg.mean())

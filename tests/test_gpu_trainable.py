@@ -256,3 +256,43 @@ def test_versa_model_matches_reference(variant):
     # fp16 taps on disk (GPTQ Llama caches, preprocess_llama-3-70b_micro.py) are upcast like model.py:402
     cv16, _ = model.mm_encoder(tc.half(), tt.half())
     assert cv16.dtype == torch.float32 and torch.isfinite(cv16).all()
+
+
+def test_batched_eval_pipeline_matches_reference_metrics():
+    """evaluate_ranks / hit_ndcg (device rank counting) against eval_model's Hit@10 / nDCG@10 and per-user ranks."""
+    from iisan_amd import evaluate
+    z, seqs, tables, P = gio.eval_inputs()
+    args = helpers.make_args()
+    model = helpers.build_model(args, int(z["item_num"]), torch.ones(int(z["item_num"]) + 1), cached=True)
+    helpers.load_trainables(model, {k: v for k, v in P.items() if k.startswith("user_encoder.") or k.startswith("com_dense.")})
+    item_emb = ops.LinearFn.apply(torch.cat(tables, 1).cuda(), model.com_dense.weight, model.com_dense.bias).detach()
+    ranks = evaluate.evaluate_ranks(model, item_emb, seqs, [s[:-1] for s in seqs], max_seq_len=10, batch=16).cpu().long()
+    ref = torch.from_numpy(z["ranks"])
+    in_hist = torch.tensor([s[-1] in s[:-1] for s in seqs])
+    assert torch.equal(ranks[~in_hist], ref[~in_hist])
+    hit, ndcg = evaluate.hit_ndcg(ranks)
+    assert abs(hit - float(z["hit10"])) < 1e-6 and abs(ndcg - float(z["ndcg10"])) < 1e-6
+
+
+def test_tap_cache_feeds_the_cached_path_identically():
+    """Cached == Uncached given the cached taps (SURVEY.md §4 invariant 3): build_tap_cache -> CachedIISANAdaptedMModel
+    reproduces the Uncached wrapper's embeddings bit for bit."""
+    from iisan_amd import evaluate
+    z, vw, bw, b, P = gio.e2e_small_inputs()
+    args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8)
+    un = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+    helpers.load_trainables(un, P)
+    un.eval()
+    img, txt = b.images.cuda(), b.text.cuda()
+    taps_cv, taps_tx = evaluate.build_tap_cache(un, img, txt, batch=7)
+    assert taps_cv.shape == (33, 3, 768) and taps_tx.shape == (33, 3, 768)
+    ca = helpers.build_model(args, 40, b.pop_prob, cached=True)
+    Pc = {k.replace("mm_encoder.cv_encoder.image_net.classifier", "mm_encoder.cv_pre_fc")
+           .replace("mm_encoder.bert_encoder.text_encoders.title.fc", "mm_encoder.bert_pre_fc"): v for k, v in P.items()}
+    helpers.load_trainables(ca, Pc)
+    ca.eval()
+    cv_u, (tx_u, mm_u) = un.mm_encoder(img, txt)
+    cv_c, (tx_c, mm_c) = ca.mm_encoder(taps_cv, taps_tx)
+    assert torch.equal(cv_u, cv_c) and torch.equal(tx_u, tx_c) and torch.equal(mm_u, mm_c)
+    tbl = evaluate.item_table(ca, taps_cv, taps_tx, batch=10)
+    assert tbl.shape == (33, 64) and torch.isfinite(tbl).all()
