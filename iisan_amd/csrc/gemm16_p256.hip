@@ -19,6 +19,7 @@
 //   * XCD-aware tile order: the 32 workgroups of one XCD walk 32 consecutive tiles (n fastest), sharing A row
 //     panels and the weight matrix in that XCD's L2.
 #include "common.h"
+#include "gemm16_epi.h"
 
 namespace {
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
     // and all main loops (pure MFMA) would coincide chip-wide; a one-off start offset of up to ~one tile time spreads
     // the store bursts under other CUs' compute for the rest of the launch.
     if (p.debug & 4) {
-        const int units = (pid * 7919) & 15;
+        const int units = ((pid * 7919) >> 2) & 63;          // 0..48 us in 0.76 us units: spans a whole tile period
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(25);
     }
 

@@ -13,14 +13,21 @@
 //        A:      R(s)      M(s)       R(s+1)     M(s+1)
 //        B:      M(s-1)    R(s)       M(s)       R(s+1)
 //
-// so on every SIMD one wave feeds the matrix pipe while its sibling reads LDS.  ALL LDS-DMA is issued from READ
-// slots (issuing a `global_load_lds` costs the issuing wave ~60-180 cycles — measured: DMA issued from MFMA slots cost
-// 21 % of the loop — while a read slot has ~400 cycles of slack next to the sibling's 1024-cycle MFMA slot).  The ring
-// pieces are recycled independently: an A-operand half is private to its group (free when that group's R slot ends),
-// the W tile is shared (free when B's R slot ends):
-//        A, in R(s) (slot 2s)   : the whole W tile of step s+1                 (needed 2 slots later)
-//        B, in R(s) (slot 2s+1) : B's A-half of step s+1, then A's A-half of step s+2   (2 / 3 slots)
-// with counted waits only (A: vmcnt(0) at the end of M; B: vmcnt(8) at the end of R, vmcnt(4) at the end of M).
+// so on every SIMD one wave feeds the matrix pipe while its sibling reads LDS.
+//
+// Where the LDS-DMA goes was settled with tools/micro/slot_dma.hip (cycles per K-step on one CU, 2048 = MFMA bound):
+//   8 `global_load_lds` per wave at the head of the read slot 3592, after the ds_reads 2754, 4 + 4 split 2741,
+//   ALL 8 INTERLEAVED WITH THE MFMAs (one after every 4) AND WAITED FOR ONE SLOT LATER: 2168.
+// What costs is a wave waiting for its own loads or queueing at the texture addresser next to ds_reads, not the issue
+// among MFMAs.  So read slots hold only the 24 ds_reads plus the wait, MFMA slots issue the DMA, and every piece has a
+// full slot between its issue and its wait:
+//        A in M(s)   (slot 2s+1) : B's A-operand half of step s+1 (read in slot 2s+3), A's own half of step s+2 (2s+4)
+//        B in M(s)   (slot 2s+2) : the whole W tile of step s+2   (read in slots 2s+4, 2s+5)
+//        A and B: `s_waitcnt vmcnt(0)` at the END of each read slot (so the stores of an epilogue get a slot as well)
+// Each ring buffer was last read at least one slot before it is overwritten (2 stages of 64 KiB).
+// The compiler must be fenced (`sched_barrier`) around every barrier / wait: MFMAs are pure register ops, and without
+// the fences 28 of group B's 32 MFMAs were hoisted above the `s_barrier` into its read slot and the `s_waitcnt vmcnt`
+// to the top of the MFMA slot — turning the stagger back into lock-step (seen in the ISA, cost ~10 %).
 // Tile walk, LDS swizzle, operand swap / W-row permutation and the 16-bit epilogues are those of gemm16_p256.hip.
 #include "common.h"
 
@@ -42,8 +49,19 @@ template <> struct Mfma32s<BF16> {
 
 __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 2) & 1) + 4 * ((q & 31) >> 3) + (q & 3); }
 
-#define S256_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define S256_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define S256_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define S256_BARRIER()                                   \
+    do {                                                 \
+        S256_FENCE();                                    \
+        asm volatile("s_barrier" ::: "memory");          \
+        S256_FENCE();                                    \
+    } while (0)
+#define S256_VMCNT(n)                                        \
+    do {                                                     \
+        S256_FENCE();                                        \
+        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
+        S256_FENCE();                                        \
+    } while (0)
 #define S256_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <typename T, int EPI>
@@ -76,29 +94,23 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     const char* Abase = (const char*)p.A;
     const char* Wbase = (const char*)p.W;
 
-    // group B: half `h` (0 = A's rows 0..127, 1 = B's rows 128..255) of the A-operand tile of flat step s;
-    // wave wq stages rows h*128 + wq*32 .. +31 as 4 chunks of 8 rows
-    auto issue_Ahalf = [&](int s, int h) {
+    // One 1-KiB piece (8 LDS rows) of the A-operand half `h` / the W half `h` of flat step s; wave wq owns rows
+    // h*128 + wq*32 .. +31 of a half, piece j = rows +8j.
+    auto piece_A = [&](int s, int h, int j) {
         const int ti = s / nk, kt = s - ti * nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n;
         const int q0 = h * 128 + wq * 32;
-        const char* Ag = Abase + (((int64_t)tm * SBM + q0) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
-        char* sA = smem + (s & 1) * S_STAGE_BYTES + q0 * 128;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(Ag + j * 8 * p.lda * 2 + ((j & 1) ? slotx1 : slotx0), sA + j * 1024);
+        const char* Ag = Abase + (((int64_t)tm * SBM + q0 + 8 * j) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
+        glds16(Ag + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + (q0 + 8 * j) * 128);
     };
-    // group A: the whole W tile of flat step s; wave wq stages LDS rows wq*64 .. +63 as 8 chunks
-    auto issue_Wtile = [&](int s) {
+    auto piece_W = [&](int s, int h, int j) {   // LDS rows q0+8j.. hold W rows q0 + 4j + {0,16} + {0..3} (nperm32s)
         const int ti = s / nk, kt = s - ti * nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
-        const int q0 = wq * 64;
-        const char* Wg = Wbase + (((int64_t)tn * SBN + q0) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
-        char* sW = smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + q0 * 128;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)      // chunk j: LDS rows q0+8j.. -> W rows q0 + 32*(j>>2) + 4*(j&3) + {0,16}+{0..3}
-            glds16(Wg + (32 * (j >> 2) + 4 * (j & 3)) * p.ldw * 2 + ((j & 1) ? slotx1 : slotx0), sW + j * 1024);
+        const int q0 = h * 128 + wq * 32;
+        const char* Wg = Wbase + (((int64_t)tn * SBN + q0 + 4 * j) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
+        glds16(Wg + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (q0 + 8 * j) * 128);
     };
 
     f16v acc[4][2];
@@ -130,13 +142,56 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             for (int mi = 0; mi < 4; ++mi) xf[mi][ks] = *(const V8*)(sA + xoff[mi] + slot);
         }
     };
-    auto mfma_step = [&]() {
+    // 32 MFMAs with this wave's 8 DMA pieces interleaved, one after every 4 MFMAs.  Group A: pieces 0..3 = B's
+    // A-operand half of step s1 (if d1), 4..7 = A's own half of step s2 (if d2); group B: the W tile of step s2 (if d2).
+    auto mfma_step = [&](int s1, bool d1, int s2, bool d2) {
+        // wave-uniform bases first (scalar divisions), so that only adds sit between the MFMAs
+        const char* g1 = nullptr; const char* g2 = nullptr;
+        char* l1 = nullptr; char* l2 = nullptr;
+        int64_t gstep = 0;
+        if (grp == 0) {
+            if (d1) {
+                const int ti = s1 / nk, kt = s1 - ti * nk;
+                const int tm = (pid + ti * G) / tiles_n;
+                g1 = Abase + (((int64_t)tm * SBM + 128 + wq * 32) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
+                l1 = smem + (s1 & 1) * S_STAGE_BYTES + (128 + wq * 32) * 128;
+            }
+            if (d2) {
+                const int ti = s2 / nk, kt = s2 - ti * nk;
+                const int tm = (pid + ti * G) / tiles_n;
+                g2 = Abase + (((int64_t)tm * SBM + wq * 32) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
+                l2 = smem + (s2 & 1) * S_STAGE_BYTES + (wq * 32) * 128;
+            }
+            gstep = (int64_t)8 * p.lda * 2;
+        } else if (d2) {
+            const int ti = s2 / nk, kt = s2 - ti * nk;
+            const int tau = pid + ti * G;
+            const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+            g2 = Wbase + (((int64_t)tn * SBN + wq * 32) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
+            l2 = smem + (s2 & 1) * S_STAGE_BYTES + S_OP_BYTES + (wq * 32) * 128;
+            gstep = (int64_t)4 * p.ldw * 2;
+        }
+        S256_FENCE();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Mfma32s<T>::run(wf[ni][ks], xf[mi][ks], acc[mi][ni]);
+                if (mi & 1) {
+                    const int pc = ks * 2 + (mi >> 1);          // 0..7
+                    const int j = pc & 3;
+                    S256_FENCE();
+                    if (grp == 0) {
+                        if (pc < 4) { if (d1) glds16(g1 + j * gstep + ((j & 1) ? slotx1 : slotx0), l1 + j * 1024); }
+                        else if (d2) glds16(g2 + j * gstep + ((j & 1) ? slotx1 : slotx0), l2 + j * 1024);
+                    } else if (d2) {
+                        // W half pc>>2: LDS rows +128, global rows +128
+                        glds16(g2 + (int64_t)(pc >> 2) * 128 * p.ldw * 2 + j * gstep + ((j & 1) ? slotx1 : slotx0), l2 + (pc >> 2) * 128 * 128 + j * 1024);
+                    }
+                    S256_FENCE();
+                }
+            }
     };
     auto epilogue = [&](int s) {
         const int ti = s / nk;
@@ -184,18 +239,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     };
 
     const bool nodma = (p.debug & 2) != 0;     // ablation: reuse stale LDS, no steady-state DMA
+    if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
+        const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     if (p.bias)
         for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias[i];
     __syncthreads();
 
-    // ---- prologue: step 0 and the pieces of step 1 that the steady-state rules would have issued before slot 0 ----
+    // ---- prologue: what the steady-state rules would have issued before slot 0 ----
     if (grp == 0) {
-        issue_Wtile(0);
+        for (int j = 0; j < 4; ++j) piece_W(0, 0, j);
+        for (int j = 0; j < 4; ++j) piece_A(0, 1, j);
         S256_VMCNT(0);
     } else {
-        issue_Ahalf(0, 0);
-        issue_Ahalf(0, 1);
-        if (nsteps > 1) { issue_Ahalf(1, 0); S256_VMCNT(4); } else { S256_VMCNT(0); }
+        for (int j = 0; j < 4; ++j) piece_A(0, 0, j);
+        for (int j = 0; j < 4; ++j) piece_W(0, 1, j);
+        if (nsteps > 1) {
+            for (int j = 0; j < 4; ++j) piece_A(1, 0, j);
+            for (int j = 0; j < 8; ++j) piece_W(1, j >> 2, j & 3);
+            S256_VMCNT(12);
+        } else {
+            S256_VMCNT(0);
+        }
     }
     S256_BARRIER();                                   // P: W(0) and both A-halves of step 0 are in LDS
 
@@ -203,13 +269,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         // ================= group A =================
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s : R(s) ----
-            if (s + 1 < nsteps && !nodma) issue_Wtile(s + 1);
             read_step(s);
             S256_LGKM0();
+            S256_VMCNT(0);                            // B's half of step s and A's half of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+1 : M(s) ----
-            mfma_step();
-            S256_VMCNT(0);                            // W(s+1) landed (B's loads guarantee the A-halves)
+            mfma_step(s + 1, s + 1 < nsteps && !nodma, s + 2, s + 2 < nsteps && !nodma);
             const int kt = s % nk;
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
@@ -217,26 +282,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         S256_BARRIER();                               // matches B's last slot
     } else {
         // ================= group B (one slot behind) =================
-        S256_BARRIER();                               // slot 0
+        S256_BARRIER();                               // slot 0 (W(1) was issued in the prologue)
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s+1 : R(s) ----
-            if (!nodma) {
-                if (s + 1 < nsteps) issue_Ahalf(s + 1, 1);
-                if (s + 2 < nsteps) issue_Ahalf(s + 2, 0);
-            }
             read_step(s);
             S256_LGKM0();
-            // A's A-half of step s+1 (issued one R slot ago) must be in LDS before A's R(s+1) in the next slot; the
-            // loads issued in THIS slot may stay in flight
-            if (nodma) S256_VMCNT(0);
-            else if (s + 2 < nsteps) S256_VMCNT(8);
-            else if (s + 1 < nsteps) S256_VMCNT(4);
-            else S256_VMCNT(0);
+            S256_VMCNT(0);                            // the W tile of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+2 : M(s) ----
-            mfma_step();
-            // B's own A-half of step s+1 (first of the two batches issued in R(s)) before R(s+1)
-            if (s + 2 < nsteps && !nodma) S256_VMCNT(4); else S256_VMCNT(0);
+            mfma_step(0, false, s + 2, s + 2 < nsteps && !nodma);
             const int kt = s % nk;
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
