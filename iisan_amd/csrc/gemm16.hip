@@ -206,9 +206,9 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const int var = g_variant & 0xff;
     const bool big = var == 2 || var == 3 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
-    // auto policy (micro-benchmarks, tools/gemm_time.py): the staggered kernel wins on the K=768 plain-epilogue GEMMs
-    // (QKV, O), the lock-step one on the GELU epilogue and on K=3072
-    if (big && (var == 3 || (var == 0 && g_auto_staggered && mode != EPI_GELU16 && a.K <= 1536)) && gemm16_s256_applicable(mode, a)) {
+    // auto policy (micro-benchmarks, tools/gemm_time.py): the staggered kernel wins on all four encoder GEMM shapes;
+    // the lock-step one takes what the staggered one does not cover (fp32 / residual epilogues)
+    if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
         rc = launch_gemm16_s256(dtype16, mode, b, s);

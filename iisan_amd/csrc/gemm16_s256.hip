@@ -30,6 +30,7 @@
 // to the top of the MFMA slot — turning the stagger back into lock-step (seen in the ISA, cost ~10 %).
 // Tile walk, LDS swizzle, operand swap / W-row permutation and the 16-bit epilogues are those of gemm16_p256.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -142,61 +143,98 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             for (int mi = 0; mi < 4; ++mi) xf[mi][ks] = *(const V8*)(sA + xoff[mi] + slot);
         }
     };
-    // 32 MFMAs with this wave's 8 DMA pieces interleaved, one after every 4 MFMAs.  Group A: pieces 0..3 = B's
-    // A-operand half of step s1 (if d1), 4..7 = A's own half of step s2 (if d2); group B: the W tile of step s2 (if d2).
-    auto mfma_step = [&](int s1, bool d1, int s2, bool d2) {
-        // wave-uniform bases first (scalar divisions), so that only adds sit between the MFMAs
-        const char* g1 = nullptr; const char* g2 = nullptr;
-        char* l1 = nullptr; char* l2 = nullptr;
-        int64_t gstep = 0;
+    // ---- DMA plan of one MFMA slot: 8 wave-uniform (global address, LDS offset) pairs, computed in the preceding READ
+    // slot (which idles ~1000 cycles at its barrier).  Nothing but the MFMAs, one 64-bit add, `s_mov m0` and the
+    // `global_load_lds` itself may sit in the MFMA slot: slot timelines showed every scalar instruction or branch between
+    // MFMAs to cost matrix-pipe time (an MFMA slot took 1440 cycles with 8 skipped `if`s, 1540 with 32, 1046 bare).
+    // The plan is therefore unconditional: past the end of the workgroup's steps it re-loads the last step into
+    // buffers that nobody reads any more.
+    struct Plan {
+        uint32_t g1lo, g1hi, g2lo, g2hi;      // global byte address of pieces 0..3 / 4..7 (SGPRs)
+        uint32_t l1, l2;                      // LDS byte offset of piece 0 / piece 4
+    };
+    // per-lane source offset of piece j (j = pc & 3): row-in-chunk and swizzled 16-B slot, plus j chunks of 8 (A operand)
+    // or 4 (permuted W) rows
+    uint32_t vj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        vj[j] = (uint32_t)((grp == 0 ? rowA : rowW) + ((j & 1) ? slotx1 : slotx0)) + (uint32_t)j * (grp == 0 ? 8u * p.lda * 2u : 4u * p.ldw * 2u);
+    auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // Group A: pieces 0..3 = B's A-operand half of step s+1, 4..7 = A's own half of step s+2;
+    // group B: the W tile of step s+2 (pieces 0..3 rows 0..127, 4..7 rows 128..255).
+    auto make_plan = [&](int s) {
+        Plan q;
+        const int last = nsteps - 1;
+        uint64_t g1, g2;
         if (grp == 0) {
-            if (d1) {
-                const int ti = s1 / nk, kt = s1 - ti * nk;
-                const int tm = (pid + ti * G) / tiles_n;
-                g1 = Abase + (((int64_t)tm * SBM + 128 + wq * 32) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
-                l1 = smem + (s1 & 1) * S_STAGE_BYTES + (128 + wq * 32) * 128;
-            }
-            if (d2) {
-                const int ti = s2 / nk, kt = s2 - ti * nk;
-                const int tm = (pid + ti * G) / tiles_n;
-                g2 = Abase + (((int64_t)tm * SBM + wq * 32) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
-                l2 = smem + (s2 & 1) * S_STAGE_BYTES + (wq * 32) * 128;
-            }
-            gstep = (int64_t)8 * p.lda * 2;
-        } else if (d2) {
+            const int s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last;
+            const int ti1 = s1 / nk, kt1 = s1 - ti1 * nk, tm1 = (pid + ti1 * G) / tiles_n;
+            const int ti2 = s2 / nk, kt2 = s2 - ti2 * nk, tm2 = (pid + ti2 * G) / tiles_n;
+            g1 = (uint64_t)Abase + (((int64_t)tm1 * SBM + 128 + wq * 32) * p.lda + (int64_t)kt1 * SBK) * 2;
+            g2 = (uint64_t)Abase + (((int64_t)tm2 * SBM + wq * 32) * p.lda + (int64_t)kt2 * SBK) * 2;
+            q.l1 = ((s + 1) & 1) * S_STAGE_BYTES + (128 + wq * 32) * 128;
+            q.l2 = (s & 1) * S_STAGE_BYTES + (wq * 32) * 128;
+        } else {
+            const int s2 = s + 2 < last ? s + 2 : last;
             const int ti = s2 / nk, kt = s2 - ti * nk;
             const int tau = pid + ti * G;
             const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
-            g2 = Wbase + (((int64_t)tn * SBN + wq * 32) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
-            l2 = smem + (s2 & 1) * S_STAGE_BYTES + S_OP_BYTES + (wq * 32) * 128;
-            gstep = (int64_t)4 * p.ldw * 2;
+            g1 = (uint64_t)Wbase + (((int64_t)tn * SBN + wq * 32) * p.ldw + (int64_t)kt * SBK) * 2;
+            g2 = g1 + (uint64_t)128 * p.ldw * 2;
+            q.l1 = (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (wq * 32) * 128;
+            q.l2 = q.l1 + 128 * 128;
         }
+        q.g1lo = sgpr((uint32_t)g1); q.g1hi = sgpr((uint32_t)(g1 >> 32));
+        q.g2lo = sgpr((uint32_t)g2); q.g2hi = sgpr((uint32_t)(g2 >> 32));
+        q.l1 = sgpr(q.l1); q.l2 = sgpr(q.l2);
+        return q;
+    };
+    // 32 MFMAs with this wave's 8 DMA pieces interleaved: piece pc after MFMA 4*pc + 3.  Only the 8 MFMAs of K-slice 0
+    // exist in two versions (a tile's first K-step starts from C = 0, an inline-constant operand, instead of zeroing
+    // 128 VGPRs): with two full bodies the compiler hoisted the 8 piece addresses above the branch -> 16 VGPRs, spills,
+    // and a `s_waitcnt vmcnt(0)` for the reload at the top of every MFMA slot.
+    auto mfma_step = [&](const Plan& q, bool first) {
+        auto piece = [&](int pc) {
+            const int j = pc & 3;
+            const uint64_t gb = ((uint64_t)(pc < 4 ? q.g1hi : q.g2hi) << 32) | (pc < 4 ? q.g1lo : q.g2lo);
+            S256_FENCE();
+            glds16((const char*)gb + vj[j], smem + (pc < 4 ? q.l1 : q.l2) + j * 1024);
+            S256_FENCE();
+        };
+        auto slice = [&](auto FIRST, int ks) {
+            f16v zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = Mfma32s<T>::run(wf[ni][ks], xf[mi][ks], decltype(FIRST)::value ? zero : acc[mi][ni]);
+                    if (((mi * 2 + ni) & 3) == 3) piece(ks * 2 + (mi >> 1));
+                }
+        };
+        if (first) slice(std::true_type{}, 0); else slice(std::false_type{}, 0);
         S256_FENCE();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Mfma32s<T>::run(wf[ni][ks], xf[mi][ks], acc[mi][ni]);
-                if (mi & 1) {
-                    const int pc = ks * 2 + (mi >> 1);          // 0..7
-                    const int j = pc & 3;
-                    S256_FENCE();
-                    if (grp == 0) {
-                        if (pc < 4) { if (d1) glds16(g1 + j * gstep + ((j & 1) ? slotx1 : slotx0), l1 + j * 1024); }
-                        else if (d2) glds16(g2 + j * gstep + ((j & 1) ? slotx1 : slotx0), l2 + j * 1024);
-                    } else if (d2) {
-                        // W half pc>>2: LDS rows +128, global rows +128
-                        glds16(g2 + (int64_t)(pc >> 2) * 128 * p.ldw * 2 + j * gstep + ((j & 1) ? slotx1 : slotx0), l2 + (pc >> 2) * 128 * 128 + j * 1024);
-                    }
-                    S256_FENCE();
-                }
-            }
+        for (int ks = 1; ks < 4; ++ks) slice(std::false_type{}, ks);
     };
     auto epilogue = [&](int s) {
         const int ti = s / nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+        // head-major QKV: this wave's 64 columns are one (q|k|v, head) pair -> wave-uniform; (item, token) of a row by
+        // ONE 32-bit division per tile, then advanced by 32 rows per block (a 64-bit division per block cost ~800
+        // VALU instructions per tile and wave)
+        unsigned qk_which = 0, qk_hd = 0, qk_item = 0, qk_tok = 0;
+        const unsigned qk_S = (unsigned)p.qkv_S;
+        if constexpr (EPI == EPI_QKVH16) {
+            const unsigned Dm = (unsigned)p.qkv_heads * 64u, n64 = (unsigned)(tn * SBN + wq * 64);
+            qk_which = n64 / Dm;
+            qk_hd = (n64 - qk_which * Dm) >> 6;
+            const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + frow);
+            qk_item = m0 / qk_S;
+            qk_tok = m0 - qk_item * qk_S;
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int64_t m = (int64_t)tm * SBM + grp * 128 + mi * 32 + frow;
@@ -206,8 +244,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
                 if (m >= p.M || (p.debug & 1)) continue;
                 if (p.bias) {
 #pragma unroll
@@ -219,11 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                 }
                 typename T::elem* op;
                 if constexpr (EPI == EPI_QKVH16) {
-                    const int Dm = p.qkv_heads * 64;
-                    const int64_t item = m / p.qkv_S;
-                    const int tok = (int)(m - item * p.qkv_S);
-                    const int which = n / Dm, hd = (n - which * Dm) >> 6, d = n & 63;
-                    op = (typename T::elem*)p.out + (((item * p.qkv_heads + hd) * 3 + which) * p.qkv_S + tok) * 64 + d;
+                    op = (typename T::elem*)p.out + ((((int64_t)qk_item * p.qkv_heads + qk_hd) * 3 + qk_which) * qk_S + qk_tok) * 64 + (ni * 32 + 16 * fh);
                 } else {
                     op = (typename T::elem*)p.out + m * p.ldo + n;
                 }
@@ -235,10 +267,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                     *(V8*)(op + 8 * h2) = o;
                 }
             }
+            if constexpr (EPI == EPI_QKVH16) {
+                qk_tok += 32;
+                while (qk_tok >= qk_S) { qk_tok -= qk_S; ++qk_item; }
+            }
         }
+        // the accumulators are dead now (the next K-step is a tile's first and starts from C = 0); an empty asm that
+        // "defines" them tells the register allocator so — otherwise it copies all 128 of them before the bias add
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) asm volatile("" : "=v"(acc[mi][ni]));
     };
 
     const bool nodma = (p.debug & 2) != 0;     // ablation: reuse stale LDS, no steady-state DMA
+    const long long dbg_t0 = __builtin_readcyclecounter();
     if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
@@ -270,12 +313,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s : R(s) ----
             read_step(s);
+            const int kt = s % nk;
+            const Plan q = make_plan(s);
             S256_LGKM0();
             S256_VMCNT(0);                            // B's half of step s and A's half of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+1 : M(s) ----
-            mfma_step(s + 1, s + 1 < nsteps && !nodma, s + 2, s + 2 < nsteps && !nodma);
-            const int kt = s % nk;
+            mfma_step(q, kt == 0);
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
         }
@@ -286,15 +330,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s+1 : R(s) ----
             read_step(s);
+            const int kt = s % nk;
+            const Plan q = make_plan(s);
             S256_LGKM0();
             S256_VMCNT(0);                            // the W tile of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+2 : M(s) ----
-            mfma_step(0, false, s + 2, s + 2 < nsteps && !nodma);
-            const int kt = s % nk;
+            mfma_step(q, kt == 0);
             if (kt == nk - 1) epilogue(s);
             S256_BARRIER();
         }
+    }
+    if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
+        ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
+        ((long long*)p.out)[2 * blockIdx.x + 1] = nsteps;
     }
 }
 

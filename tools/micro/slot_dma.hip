@@ -11,7 +11,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 #define SB() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
-template <int NR, int NM, int POS>
+template <int NR, int NM, int POS, int ADDR = 0>
 __global__ __launch_bounds__(512) void k(const char* src, long long* cyc, float* sink, int iters, int win) {
     extern __shared__ char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = wave >> 2;
@@ -22,6 +22,11 @@ __global__ __launch_bounds__(512) void k(const char* src, long long* cyc, float*
     h8 fr[24];
     for (int j = 0; j < 24; ++j) fr[j] = *(const h8*)(smem + lane * 16 + j * 1024);
     const char* base = smem + (wave & 3) * 24 * 1024 + lane * 16;
+    // GEMM-like: fragment row = lane&31 (128-B pitch), 16-B slot (2*ks + (lane>>5)) ^ ((row>>1)&7); group g reads its A half
+    const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+    const char* gA = smem + grp * 16384 + frow * 128;                  // + mi*4096
+    const char* gW = smem + 32768 + (wave & 3) * 8192 + frow * 128;      // + ni*4096
+    unsigned stage = 0;
     char* dst = smem + 96 * 1024 + wave * 4096;          // DMA destination (not read: timing only)
     const char* g = src + (long)blockIdx.x * win + wave * 8192 + lane * 16;
     unsigned off = 0;
@@ -32,7 +37,14 @@ __global__ __launch_bounds__(512) void k(const char* src, long long* cyc, float*
         if (POS == 0) { for (int j = 0; j < NR; ++j) dma(j); }
 #pragma unroll
         for (int j = 0; j < 24; ++j) {
-            fr[j] = *(const h8*)(base + j * 1024);
+            if (ADDR == 0) fr[j] = *(const h8*)(base + j * 1024);
+            else {
+                // order as in gemm16_s256: per ks: wf[0], wf[1], xf[0..3]  -> fr index: W: (ni)*4+ks, A: 8 + mi*4 + ks
+                const int ks = j / 6, w = j % 6;
+                const int slot = ((2 * ks + fh) ^ fsw) << 4;
+                if (w < 2) fr[w * 4 + ks] = *(const h8*)(gW + stage + w * 4096 + slot);
+                else fr[8 + (w - 2) * 4 + ks] = *(const h8*)(gA + stage + (w - 2) * 4096 + slot);
+            }
             if (POS == 2 && NR > 0 && (j % (24 / (NR > 0 ? NR : 1))) == 0 && j / (24 / (NR > 0 ? NR : 1)) < NR) { FENCE(); dma(j / (24 / (NR > 0 ? NR : 1))); FENCE(); }
         }
         if (POS == 1) { FENCE(); for (int j = 0; j < NR; ++j) dma(j); }
@@ -54,6 +66,7 @@ __global__ __launch_bounds__(512) void k(const char* src, long long* cyc, float*
         else if (NM == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         off += 65536;
+        stage ^= 65536;
         SB();
     };
     if (grp == 0) { for (int it = 0; it < iters; ++it) body(); SB(); }
@@ -67,22 +80,22 @@ __global__ __launch_bounds__(512) void k(const char* src, long long* cyc, float*
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 const char* src; long long* cyc; float* sink;
-template <int NR, int NM, int POS>
+template <int NR, int NM, int POS, int ADDR = 0>
 void run(int grid, int win) {
-    hipFuncSetAttribute((const void*)k<NR, NM, POS>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    hipFuncSetAttribute((const void*)k<NR, NM, POS, ADDR>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
     const int iters = 4000;
     std::vector<long long> h(2048);
     float ms = 0;
     for (int it = 0; it < 2; ++it) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        k<NR, NM, POS><<<grid, 512, 136 * 1024>>>(src, cyc, sink, iters, win);
+        k<NR, NM, POS, ADDR><<<grid, 512, 136 * 1024>>>(src, cyc, sink, iters, win);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     hipMemcpy(h.data(), cyc, grid * 64, hipMemcpyDeviceToHost);
     double c = 0; for (int b = 0; b < grid; ++b) c += h[b * 8];
     c /= grid * (double)iters;
-    printf("grid=%3d win=%7d nR=%d nM=%d pos=%d: %.0f cycles per k-step (MFMA-bound = 2048), %.3f GHz, %.0f TFLOP/s\n", grid, win, NR, NM, POS, c, c * iters / (ms * 1e6),
+    printf("grid=%3d win=%7d nR=%d nM=%d pos=%d addr=%d: %.0f cycles per k-step (MFMA-bound = 2048), %.3f GHz, %.0f TFLOP/s\n", grid, win, NR, NM, POS, ADDR, c, c * iters / (ms * 1e6),
            (double)grid * 8 * 32 * 32768.0 * iters / (ms * 1e-3) / 1e12);
 }
 int main() {
@@ -91,6 +104,8 @@ int main() {
     for (int grid : {1, 256})
     for (int win : {65536}) {
         run<0, 0, 0>(grid, win);
+        run<0, 0, 0, 1>(grid, win);
+        run<0, 8, 1, 1>(grid, win);
         run<8, 0, 1>(grid, win);
         run<6, 2, 1>(grid, win);
         run<4, 4, 1>(grid, win);
