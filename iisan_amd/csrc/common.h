@@ -104,11 +104,34 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // Used only where the result is rounded to a 16-bit operand anyway (FC1 epilogue of the frozen encoders).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     const float erf_x = copysignf(erf_abs, x);
     return 0.5f * x * (1.0f + erf_x);
+}
+// Two GELUs at once on the packed-fp32 VALU path (v_pk_fma_f32 / v_pk_mul_f32: 2 results per instruction) with a single
+// transcendental per value: erf by Abramowitz-Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16 (|err| <= 3e-7;
+// measured max |gelu error| 7e-7 over [-12, 12]), and gelu(x) = max(x, 0) - 0.5 |x| (1 - erf(|x|/sqrt2)).
+// The 7.1.26 form above costs ~84 VALU cycles per value (rcp + exp at quarter rate, nothing packed), this one ~45; the
+// FC1 epilogue evaluates 128 of them per lane and tile.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 gelu_erf_fast2(f2 x) {
+    f2 ax;
+    ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    const f2 z = ax * 0.70710678118654752440f;
+    f2 p = __builtin_elementwise_fma(z, (f2)0.0000430638f, (f2)0.0002765672f);
+    p = __builtin_elementwise_fma(p, z, (f2)0.0001520143f);
+    p = __builtin_elementwise_fma(p, z, (f2)0.0092705272f);
+    p = __builtin_elementwise_fma(p, z, (f2)0.0422820123f);
+    p = __builtin_elementwise_fma(p, z, (f2)0.0705230784f);
+    p = __builtin_elementwise_fma(p, z, (f2)1.0f);
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    f2 r;
+    r[0] = __builtin_amdgcn_rcpf(p[0]); r[1] = __builtin_amdgcn_rcpf(p[1]);      // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
+    f2 mx;
+    mx[0] = fmaxf(x[0], 0.f); mx[1] = fmaxf(x[1], 0.f);
+    return __builtin_elementwise_fma(ax * -0.5f, r, mx);
 }
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
