@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type of the frozen encoders")
     ap.add_argument("--chunk", type=int, default=0, help="items per encoder chunk (0 = whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-blocks", action="store_true",
+                    help="ablation: run every encoder block on every token like HF does (default: the last block computes "
+                         "attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed; same taps)")
     return ap.parse_args()
 
 
@@ -101,6 +104,7 @@ def main():
     import helpers
     from iisan_amd import _lib, encoders, synth, trainer, weights
     lib = _lib.load()
+    lib.iisan_set_full_blocks(1 if a.full_blocks else 0)
 
     args = helpers.make_args()
     batch = synth.scientific_batch(bs=a.bs, seed=12345 + rank, device=dev, images_on_device=True)
@@ -153,10 +157,12 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "Code_Uncached IISAN ViT-base+BERT-base, Amazon-Scientific-shaped synthetic batch, "
                                    f"bs={a.bs}/GPU ({slots} item slots, all encoded), 1xMI355X per rank",
-                       "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item())},
+                       "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
+                       "encoder_blocks": "all tokens in every block (as HF)" if a.full_blocks else
+                                         "last block: K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_tflops / (MFMA_PEAK / 1e12), "traffic": None,
-                         "kernel": "gemm16_kernel (QKV/O/FC1/FC2/patch GEMMs of the frozen encoders)",
+                         "kernel": "gemm16 (gemm16_s256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders; flops = executed, by launch)",
                          "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                          "flop_per_launch": fl.value / max(n_launch, 1),
                          "whole_step_frac": value / world * FLOP_PER_SLOT / MFMA_PEAK},

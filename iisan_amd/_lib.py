@@ -72,6 +72,8 @@ SIGNATURES = {
     "iisan_gemm16": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_layernorm768": (i32, [i32, vp, vp, vp, f32, vp, vp, i64, vp]),
     "iisan_attention16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_attention_cls16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
+    "iisan_set_full_blocks": (None, [i32]),
     "iisan_gemm32": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp]),
     "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
 }

@@ -217,6 +217,90 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
     }
 }
 
+// ---- CLS-query attention for the LAST executed encoder block --------------------------------------------------------
+// The hot path consumes only `hidden_states[i][:, 0]` (Code_Uncached/model/model.py:210-213), so in the last block the
+// outputs of every non-CLS token are dead: K and V are still needed for all tokens, but attention, O, the MLP and the
+// LayerNorms run for one query per item.  One wave = one (item, head): phase 1 lanes over keys (fp32 dot products,
+// softmax statistics by wave shuffles), phase 2 lanes over (4 keys x 16 four-dim groups) streaming V rows.
+// HBM-bound: reads K and V once (2 * S * 128 B per pair).  P is rounded to the 16-bit operand type before the PV
+// product and the sum uses the unrounded values, as in the MFMA kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::elem* __restrict__ qkv,
+                                                            const float* __restrict__ key_bias,
+                                                            typename T::elem* __restrict__ ctx, int64_t pairs, int S, int heads) {
+    typedef typename T::elem E;
+    typedef typename T::v8 V8;
+    typedef typename T::v4 V4;
+    __shared__ float sP[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+    if (pair >= pairs) return;
+    const int64_t item = pair / heads;
+    const int h = (int)(pair - item * heads);
+    const E* qb_ = qkv + pair * 3 * S * 64;
+    const E* kb_ = qb_ + (int64_t)S * 64;
+    const E* vb_ = kb_ + (int64_t)S * 64;
+    float q[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const V8 t = *(const V8*)(qb_ + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[c * 8 + e] = T::to_f32(t[e]);
+    }
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = lane + 64 * i;
+        float a = -INFINITY;
+        if (key < S) {
+            a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const V8 t = *(const V8*)(kb_ + (int64_t)key * 64 + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fmaf(q[c * 8 + e], T::to_f32(t[e]), a);
+            }
+            if (key_bias && key_bias[item * S + key] < 0.f) a = MASK_RAW;
+        }
+        sc[i] = a;
+        mx = fmaxf(mx, a);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float c2 = 0.18033688011112042f;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p = __builtin_amdgcn_exp2f((sc[i] - mx) * c2);      // -inf -> 0 for the structural pad keys
+        sum += p;
+        sP[wave][lane + 64 * i] = T::to_f32(T::from_f32(p));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's sP writes (each wave reads only its own row)
+    const int kg = lane >> 4, dq = lane & 15;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int key = kg; key < S; key += 4) {
+        const V4 v = *(const V4*)(vb_ + (int64_t)key * 64 + dq * 4);
+        const float p = sP[wave][key];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, T::to_f32(v[e]), acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (kg == 0) {
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = T::from_f32(acc[e] * inv);
+        *(V4*)(ctx + item * (int64_t)heads * 64 + h * 64 + dq * 4) = o;
+    }
+}
+
 template <typename T>
 int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, int S, int heads, hipStream_t s) {
     typedef typename T::elem E;
@@ -247,7 +331,25 @@ int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void
                                  : launch_t<F16>(qkv, key_bias, ctx, items, S, heads, s);
 }
 
+int launch_attention_cls16(int dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items, int S, int heads,
+                           hipStream_t s) {
+    IISAN_CHECK_SHAPE(items > 0 && S > 0 && S <= 256 && heads > 0, "attention_cls16: unsupported problem (S=%d)", S);
+    const int64_t pairs = items * heads;
+    dim3 grid((unsigned)ceil_div(pairs, 4)), block(256);
+    if (dtype16 == IISAN_BF16)
+        hipLaunchKernelGGL(attention_cls_kernel<BF16>, grid, block, 0, s, (const __bf16*)qkv, key_bias, (__bf16*)ctx_cls, pairs, S, heads);
+    else
+        hipLaunchKernelGGL(attention_cls_kernel<F16>, grid, block, 0, s, (const _Float16*)qkv, key_bias, (_Float16*)ctx_cls, pairs, S, heads);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
 extern "C" int iisan_attention16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items,
                                  int32_t S, int32_t heads, void* stream) {
     return launch_attention16(dtype16, qkv, key_bias, ctx, items, S, heads, (hipStream_t)stream);
+}
+
+extern "C" int iisan_attention_cls16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items,
+                                     int32_t S, int32_t heads, void* stream) {
+    return launch_attention_cls16(dtype16, qkv, key_bias, ctx_cls, items, S, heads, (hipStream_t)stream);
 }

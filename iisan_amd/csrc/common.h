@@ -208,6 +208,9 @@ int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, co
                             float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
+// CLS query only: ctx_cls [items, heads*64] (last executed encoder block)
+int launch_attention_cls16(int dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items, int S,
+                           int heads, hipStream_t s);
 
 struct Gemm32Prob {
     const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;

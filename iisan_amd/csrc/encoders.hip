@@ -49,6 +49,15 @@ int tap_index(const int32_t* tap_layers, int n, int layer) {
     return -1;
 }
 
+// ablation switch (bench.py --full-last-block, tests): 1 = run every block of the tower on every token, as the reference does
+int g_full_blocks = 0;
+
+int max_tap(const int32_t* tap_layers, int n) {
+    int m = 0;
+    for (int k = 0; k < n; ++k) m = tap_layers[k] > m ? tap_layers[k] : m;
+    return m;
+}
+
 int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const int32_t* tap_layers) {
     IISAN_CHECK_SHAPE(hidden == 768, "encoder hidden size must be 768 (got %d): the side network is 768 wide "
                       "(Code_Uncached/model/model.py:171)", hidden);
@@ -62,6 +71,8 @@ int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const i
 }
 
 }  // namespace
+
+extern "C" void iisan_set_full_blocks(int32_t on) { g_full_blocks = on; }
 
 extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items) {
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
@@ -105,25 +116,45 @@ extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* i
         // The O / FC2 GEMMs emit 16-bit deltas; the fp32 residual add is fused into the NEXT LayerNorm kernel
         // (HBM-bound) instead of a read-modify-write GEMM epilogue.  `pending` = a delta not yet added to X.
         const void* pending = nullptr;
-        for (int l = 0; l < w->layers; ++l) {
+        // Blocks after the deepest tapped hidden state are dead code (Versa configurations tap a prefix of the tower),
+        // and in the last LIVE block only the CLS token's output is consumed: K/V are computed for every token, but
+        // attention, O, LN2, FC1, FC2 and the closing residual add run on one row per item.
+        const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);
+        for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // x (+= FC2 delta of layer l-1) ; h = LN1(x)            -> X is hidden state l
             IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, L.ln1_w, L.ln1_b, w->eps, pending ? b.X : nullptr, b.H, nullptr, tok, s));
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
             IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
-            IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
-            // x += O delta ; h = LN2(x)
-            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, b.X, b.H, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
-            pending = b.D16;
+            if (l + 1 < live || g_full_blocks) {
+                IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
+                // x += O delta ; h = LN2(x)
+                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, b.X, b.H, nullptr, tok, s));
+                IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
+                pending = b.D16;
+            } else {
+                // CLS rows only; compact [mc, *] views at the front of the (now free) big buffers
+                float* Xc = (float*)b.QKV;      // free once the CLS attention has run (stream order)
+                IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
+                IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
+                IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln2_w, L.ln2_b, w->eps, Xc, b.H, nullptr, mc, s));
+                IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, mc, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, mc, s));
+                IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, nullptr, nullptr, w->eps, Xc, nullptr, nullptr, mc, s));
+                k = tap_index(tap_layers, n_taps, live);     // hidden state `live` (before any final LayerNorm)
+                IISAN_TRY(launch_gather_cls(Xc, tp, mc, 1, D, n_taps, k, s));
+            }
         }
-        k = tap_index(tap_layers, n_taps, w->layers);
-        if (k >= 0) {   // last hidden state (before the final LayerNorm): only its CLS rows are needed
-            IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
-            IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        if (g_full_blocks) {
+            k = tap_index(tap_layers, n_taps, w->layers);
+            if (k >= 0) {
+                IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
+                IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            }
         }
     }
     return IISAN_OK;
@@ -161,19 +192,33 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                                        w->emb_ln_b, w->eps, b.X, b.H, b.KB, mc, T, w->vocab, s));
         int k = tap_index(tap_layers, n_taps, 0);
         if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
-        for (int l = 0; l < w->layers; ++l) {
+        const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);     // see the ViT executor
+        for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // a = LN(x + O(attn(x)))
             IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
-            IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
-            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, b.X, tok, s));
-            // x = LN(a + FC2(gelu(FC1 a)))
-            IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
-            IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
-            IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, b.X, tok, s));
-            k = tap_index(tap_layers, n_taps, l + 1);
-            if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            if (l + 1 < live || g_full_blocks) {
+                IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
+                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, b.X, tok, s));
+                // x = LN(a + FC2(gelu(FC1 a)))
+                IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
+                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, b.X, tok, s));
+                k = tap_index(tap_layers, n_taps, l + 1);
+                if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            } else {
+                float* Xc = (float*)b.QKV;
+                IISAN_TRY(launch_attention_cls16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
+                IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
+                IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, Xc, mc, s));
+                IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, mc, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, mc, s));
+                IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, nullptr, Xc, mc, s));
+                k = tap_index(tap_layers, n_taps, live);
+                IISAN_TRY(launch_gather_cls(Xc, tp, mc, 1, D, n_taps, k, s));
+            }
         }
     }
     return IISAN_OK;

@@ -96,6 +96,13 @@ int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, in
                             const int32_t* tap_layers, int32_t n_taps, float* taps,
                             int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
 
+/* Dead-work policy of the two executors above.  By default (0) blocks deeper than the deepest tapped hidden state are
+ * not run, and in the last live block attention / O / MLP / LayerNorm run for the CLS row of every item only (K and V
+ * still for all tokens): the path consumes nothing but `hidden_states[i][:, 0]`, so the taps are the same values.
+ * 1 = run every block on every token exactly like HF ViTModel / BertModel do (verification and ablation;
+ * `bench.py --full-blocks`).  Process-wide. */
+void iisan_set_full_blocks(int32_t on);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Side network (IISANAdaptedMModel.forward, Code_Uncached/model/model.py:209-271; Cached model.py:300-349).
  * All fp32.  Parameters arrive as a host array of device pointers in the order documented at
@@ -218,6 +225,10 @@ int iisan_layernorm768(int32_t dtype16, const float* x, const float* g, const fl
  * key_bias fp32 [items,S] or NULL (values < 0 mark masked keys) */
 int iisan_attention16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int32_t S,
                       int32_t heads, void* stream);
+/* the same for the CLS query (token 0) of every item only: ctx_cls 16-bit [items, H*64].  Used by the encoder executors
+ * in the last live block, where only `hidden_states[i][:, 0]` is consumed (Code_Uncached/model/model.py:210-213) */
+int iisan_attention_cls16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items,
+                          int32_t S, int32_t heads, void* stream);
 /* fp32 MFMA GEMM: C[M,N] = op(A) op(B) (+bias)(+relu); ta: A stored [K,M]; tb: B stored [K,N] (else [N,K]);
  * accumulate != 0: C += (atomic, split-K capable) */
 int iisan_gemm32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,

@@ -58,3 +58,31 @@ def test_small_config_taps_match_oracle():
     for l in (1, 2):
         assert _rel(tc[:, l], oc[:, l]) < 1.5e-3, _rel(tc[:, l], oc[:, l])
         assert _rel(tt[:, l], ot[:, l]) < 1.5e-3, _rel(tt[:, l], ot[:, l])
+
+
+def test_cls_only_last_block_matches_full_blocks(lib):
+    """Default executors skip dead work (blocks deeper than the deepest tap; non-CLS rows of the last live block);
+    `iisan_set_full_blocks(1)` runs the towers exactly like HF does.  Same taps: shallower ones bit-equal, the one
+    produced by the CLS-only block within 16-bit rounding noise of the full computation."""
+    z, vw, bw, b = gio.encoders_full_inputs()
+    vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda")
+    bert = encoders.PackedBert(bw, weights.BERT_BASE, "cuda")
+    layers = list(range(13))
+    try:
+        lib.iisan_set_full_blocks(1)
+        fc = vit.forward_taps(b.images.cuda(), layers).cpu()
+        ft = bert.forward_taps(b.text.cuda(), layers).cpu()
+    finally:
+        lib.iisan_set_full_blocks(0)
+    pc = vit.forward_taps(b.images.cuda(), layers).cpu()
+    pt = bert.forward_taps(b.text.cuda(), layers).cpu()
+    assert torch.equal(pc[:, :12], fc[:, :12]) and torch.equal(pt[:, :12], ft[:, :12])
+    assert _rel(pc[:, 12], fc[:, 12]) < 5e-4, _rel(pc[:, 12], fc[:, 12])
+    assert _rel(pt[:, 12], ft[:, 12]) < 5e-4, _rel(pt[:, 12], ft[:, 12])
+    # a tapped prefix (Versa towers): blocks 4..11 are not run at all
+    sc = vit.forward_taps(b.images.cuda(), [0, 2, 4]).cpu()
+    st = bert.forward_taps(b.text.cuda(), [0, 2, 4]).cpu()
+    assert torch.equal(sc[:, :2], fc[:, [0, 2]]) and torch.equal(st[:, :2], ft[:, [0, 2]])
+    assert _rel(sc[:, 2], fc[:, 4]) < 5e-4 and _rel(st[:, 2], ft[:, 4]) < 5e-4
+    ref_c, ref_t = torch.from_numpy(z["taps_cv"]), torch.from_numpy(z["taps_text"])
+    assert _rel(sc[:, 2], ref_c[:, 4]) < TAP_TOL[_lib.IISAN_F16] and _rel(st[:, 2], ref_t[:, 4]) < TAP_TOL[_lib.IISAN_F16]

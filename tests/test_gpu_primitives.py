@@ -124,3 +124,11 @@ def test_attention16_vs_torch(lib, dt, case):
     err = (ctx.cpu().double() - ref).abs().max().item()
     tol = 2.5 * TOL[dt] * ref.abs().max().item()     # P and O are both rounded to 16 bit
     assert err <= tol, f"attention dt={dt} {case}: max err {err:.3e} > {tol:.3e}"
+    # CLS-query-only variant (last live encoder block): row 0 of every item
+    ctx_cls = torch.empty(items, D, dtype=T16[dt], device="cuda")
+    _lib.check(lib.iisan_attention_cls16(dt, qkvd.data_ptr(), kbd.data_ptr() if kbd is not None else None,
+                                         ctx_cls.data_ptr(), items, S, heads, _stream()), "attention_cls16")
+    torch.cuda.synchronize()
+    ref_cls = ref.view(items, S, D)[:, 0]
+    err = (ctx_cls.cpu().double() - ref_cls).abs().max().item()
+    assert err <= tol, f"attention_cls dt={dt} {case}: max err {err:.3e} > {tol:.3e}"
