@@ -39,9 +39,9 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
     typedef typename T::v8 V8;
     typedef typename T::v4 V4;
     constexpr int SP = NT16 * 16;
-    // V^T row stride (elements): 132 dwords = 4 (mod 64) -> the two 8-byte reads of a half-wave (16 d-rows x 2 key
+    // V^T row stride (elements), see VT_LD below; (history: 264 = 132 dwords was chosen for a half-wave (16 d-rows x 2 key
     // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
-    constexpr int VT_LD = SP > 128 ? 264 : SP + 8;
+    constexpr int VT_LD = SP > 128 ? 260 : SP + 8;     // 130 dwords = 2 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (264 gave 2-way conflicts, PMC)
     constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
     constexpr int KP = SP / 32;                       // K passes: 32 rows per pass
     constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass

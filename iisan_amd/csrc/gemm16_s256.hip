@@ -218,10 +218,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) slice(std::false_type{}, ks);
     };
+    bool stores16 = false;     // the last epilogue issued exactly 16 store instructions per wave (full row tile, stores enabled)
     auto epilogue = [&](int s) {
         const int ti = s / nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+        stores16 = ((int64_t)(tm + 1) * SBM <= p.M) && !(p.debug & 1);
         // head-major QKV: this wave's 64 columns are one (q|k|v, head) pair -> wave-uniform; (item, token) of a row by
         // ONE 32-bit division per tile, then advanced by 32 rows per block (a 64-bit division per block cost ~800
         // VALU instructions per tile and wave)
@@ -321,7 +323,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             const int kt = s % nk;
             const Plan q = make_plan(s);
             S256_LGKM0();
-            S256_VMCNT(0);                            // B's half of step s and A's half of step s+1 (issued in M(s-1))
+            // B's half of step s and A's half of step s+1 (issued in M(s-1)) must have landed.  Right after an
+            // epilogue the 16 stores of a full tile are younger than those loads and vmcnt retires in order on gfx9, so
+            // vmcnt(16) waits for the loads only and gives the stores two more slots.
+            if (kt == 0 && s > 0 && stores16) S256_VMCNT(16); else S256_VMCNT(0);
             S256_BARRIER();
             // ---- slot 2s+1 : M(s) ----
             mfma_step(q, kt == 0);
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             const int kt = s % nk;
             const Plan q = make_plan(s);
             S256_LGKM0();
-            S256_VMCNT(0);                            // the W tile of step s+1 (issued in M(s-1))
+            if (kt == 0 && s > 0 && stores16) S256_VMCNT(16); else S256_VMCNT(0);      // the W tile of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+2 : M(s) ----
             mfma_step(q, kt == 0);
