@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         for (int ks = 1; ks < 4; ++ks) slice(std::false_type{}, ks);
     };
     bool stores16 = false;     // the last epilogue issued exactly 16 store instructions per wave (full row tile, stores enabled)
-    auto epilogue = [&](int s) {
+    auto epilogue = [&](int s, int half) {
         const int ti = s / nk;
         const int tau = pid + ti * G;
         const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
@@ -233,12 +233,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             const unsigned Dm = (unsigned)p.qkv_heads * 64u, n64 = (unsigned)(tn * SBN + wq * 64);
             qk_which = n64 / Dm;
             qk_hd = (n64 - qk_which * Dm) >> 6;
-            const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + frow);
+            const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + half * 64 + frow);
             qk_item = m0 / qk_S;
             qk_tok = m0 - qk_item * qk_S;
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
+            if ((mi >> 1) != half) continue;
             const int64_t m = (int64_t)tm * SBM + grp * 128 + mi * 32 + frow;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) asm volatile("" : "=v"(acc[mi][ni]));
+            for (int ni = 0; ni < 2; ++ni)
+                if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
     };
 
     const bool nodma = (p.debug & 2) != 0;     // ablation: reuse stale LDS, no steady-state DMA
@@ -318,9 +320,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     if (grp == 0) {
         // ================= group A =================
         for (int s = 0; s < nsteps; ++s) {
-            // ---- slot 2s : R(s) ----
-            read_step(s);
+            // ---- slot 2s : R(s) ----  (a tile's first read slot starts with the second half of the previous epilogue)
             const int kt = s % nk;
+            if (kt == 0 && s > 0) epilogue(s - 1, 1);
+            read_step(s);
             const Plan q = make_plan(s);
             S256_LGKM0();
             // B's half of step s and A's half of step s+1 (issued in M(s-1)) must have landed.  Right after an
@@ -330,26 +333,32 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             S256_BARRIER();
             // ---- slot 2s+1 : M(s) ----
             mfma_step(q, kt == 0);
-            if (kt == nk - 1) epilogue(s);
+            // Tile end.  The epilogue gets slots of its own so that it overlaps the sibling group's MFMAs instead of
+            // serialising with them:   A: M(last) | E1 | E2+R(0') | M(0')      (E1 = rows 0..63 of the group's half,
+            //                          B: R(last) | M(last) | E1 | E2+R(0')     E2 = rows 64..127)
+            if (kt == nk - 1) { S256_BARRIER(); epilogue(s, 0); }
             S256_BARRIER();
         }
+        epilogue(nsteps - 1, 1);
         S256_BARRIER();                               // matches B's last slot
     } else {
         // ================= group B (one slot behind) =================
         S256_BARRIER();                               // slot 0 (W(1) was issued in the prologue)
         for (int s = 0; s < nsteps; ++s) {
             // ---- slot 2s+1 : R(s) ----
-            read_step(s);
             const int kt = s % nk;
+            if (kt == 0 && s > 0) epilogue(s - 1, 1);
+            read_step(s);
             const Plan q = make_plan(s);
             S256_LGKM0();
             if (kt == 0 && s > 0 && stores16) S256_VMCNT(16); else S256_VMCNT(0);      // the W tile of step s+1 (issued in M(s-1))
             S256_BARRIER();
             // ---- slot 2s+2 : M(s) ----
             mfma_step(q, kt == 0);
-            if (kt == nk - 1) epilogue(s);
+            if (kt == nk - 1) { S256_BARRIER(); epilogue(s, 0); }
             S256_BARRIER();
         }
+        epilogue(nsteps - 1, 1);
     }
     if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
         ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
