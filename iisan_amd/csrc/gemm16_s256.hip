@@ -213,10 +213,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                     if (((mi * 2 + ni) & 3) == 3) piece(ks * 2 + (mi >> 1));
                 }
         };
+        // The sibling wave of this SIMD is in its read slot (ds_reads, address VALU, plan SALU): with equal priority the
+        // arbiter prefers the OLDER wave, and the slot timeline showed group B's MFMA slots at 1,680 cycles against
+        // group A's 1,252.  Priority 1 for whoever is on the matrix pipe removes that.
+        __builtin_amdgcn_s_setprio(1);
         if (first) slice(std::true_type{}, 0); else slice(std::false_type{}, 0);
         S256_FENCE();
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) slice(std::false_type{}, ks);
+        __builtin_amdgcn_s_setprio(0);
     };
     bool stores16 = false;     // the last epilogue issued exactly 16 store instructions per wave (full row tile, stores enabled)
     auto epilogue = [&](int s, int half) {
@@ -289,8 +294,23 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                 if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
     };
 
-    const bool nodma = (p.debug & 2) != 0;     // ablation: reuse stale LDS, no steady-state DMA
     const long long dbg_t0 = __builtin_readcyclecounter();
+    // development aid (build with -DS256_TIMELINE, run with debug bit 16): wave 0 of each group stamps the cycle counter
+    // at slot boundaries into LDS, dumped to out[] at the end; tools/gemm_slots.py prints the timeline.  Compiled out by
+    // default: even the disabled checks cost ~5 % (everything between MFMAs does).
+#ifdef S256_TIMELINE
+    unsigned* sStamp = (unsigned*)(smem + 2 * S_STAGE_BYTES + p.N * 4) + grp * 1024;
+    int dbg_n = 0;
+    const bool dbg_on = (p.debug & 16) && blockIdx.x == 0 && wq == 0;
+    auto stamp = [&]() {
+        if (dbg_on && dbg_n < 1024) {
+            if (lane == 0) sStamp[dbg_n] = (unsigned)(__builtin_readcyclecounter() - dbg_t0);
+            ++dbg_n;
+        }
+    };
+#else
+    auto stamp = [] {};
+#endif
     if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
@@ -330,9 +350,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             // epilogue the 16 stores of a full tile are younger than those loads and vmcnt retires in order on gfx9, so
             // vmcnt(16) waits for the loads only and gives the stores two more slots.
             if (kt == 0 && s > 0 && stores16) S256_VMCNT(16); else S256_VMCNT(0);
+            stamp();
             S256_BARRIER();
+            stamp();
             // ---- slot 2s+1 : M(s) ----
             mfma_step(q, kt == 0);
+            stamp();
             // Tile end.  The epilogue gets slots of its own so that it overlaps the sibling group's MFMAs instead of
             // serialising with them:   A: M(last) | E1 | E2+R(0') | M(0')      (E1 = rows 0..63 of the group's half,
             //                          B: R(last) | M(last) | E1 | E2+R(0')     E2 = rows 64..127)
@@ -352,14 +375,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             const Plan q = make_plan(s);
             S256_LGKM0();
             if (kt == 0 && s > 0 && stores16) S256_VMCNT(16); else S256_VMCNT(0);      // the W tile of step s+1 (issued in M(s-1))
+            stamp();
             S256_BARRIER();
+            stamp();
             // ---- slot 2s+2 : M(s) ----
             mfma_step(q, kt == 0);
+            stamp();
             if (kt == nk - 1) { S256_BARRIER(); epilogue(s, 0); }
             S256_BARRIER();
         }
         epilogue(nsteps - 1, 1);
     }
+#ifdef S256_TIMELINE
+    if (dbg_on && lane == 0)
+        for (int i = 0; i < 1024; ++i) ((unsigned*)p.out)[8192 + grp * 1024 + i] = sStamp[i];
+#endif
     if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
         ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
         ((long long*)p.out)[2 * blockIdx.x + 1] = nsteps;
@@ -381,7 +411,7 @@ int launch_epi(const Gemm16Args& a, hipStream_t s) {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int grid = (int)(ntiles < cus ? ntiles : cus);
     grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * S_STAGE_BYTES + (size_t)a.N * 4, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * S_STAGE_BYTES + (size_t)a.N * 4 + ((a.debug & 16) ? 8192 : 0), s, a, tiles_m, tiles_n);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
