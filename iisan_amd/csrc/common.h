@@ -206,6 +206,9 @@ int launch_layernorm768(int dtype16, const float* x, const float* g, const float
 // x (+ delta16) -> [sum32 = x + delta] -> LayerNorm -> out16 / out32 (any output may be null; g == null: no LayerNorm)
 int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
                             float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
+// ... with a second 16-bit delta: v = (x + delta16) + delta16b (either may be null)
+int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, const void* delta16b, const float* g,
+                             const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)

@@ -19,7 +19,8 @@ struct EncBufs {
     void* H;        // [Tp, D] 16-bit: LayerNorm output, reused as the attention context
     void* QKV;      // [Tp, 3D] 16-bit
     void* F1;       // [Tp, max(F, patch_dim)] 16-bit: GELU(FC1) (and the patch matrix during embedding)
-    void* D16;      // [Tp, D] 16-bit: output of the O / FC2 GEMMs, added to the fp32 residual stream by the next LN kernel
+    void* D16;      // [Tp, D] 16-bit: output of the O GEMM (a residual DELTA, added to the fp32 stream by LayerNorm kernels)
+    void* D16b;     // [Tp, D] 16-bit: output of the FC2 GEMM
     float* KB;      // [Mc, W] key bias (BERT)
 };
 
@@ -30,6 +31,7 @@ size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int D, int F, int64_t kb_e
     b.QKV = c.take<uint16_t>((size_t)Tp * 3 * D);
     b.F1 = c.take<uint16_t>((size_t)Tp * F);
     b.D16 = c.take<uint16_t>((size_t)Tp * D);
+    b.D16b = c.take<uint16_t>((size_t)Tp * D);
     b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
     return c.off;
 }
@@ -115,26 +117,32 @@ extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* i
         if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
         // The O / FC2 GEMMs emit 16-bit deltas; the fp32 residual add is fused into the NEXT LayerNorm kernel
         // (HBM-bound) instead of a read-modify-write GEMM epilogue.  `pending` = a delta not yet added to X.
-        const void* pending = nullptr;
+        // Residual bookkeeping (pre-LN tower): the O and FC2 GEMMs emit 16-bit deltas.  LN2 computes LN(x + dO) WITHOUT
+        // writing x back; the next LN1 adds both deltas, (x + dO) + dF in fp32 — the same value — and writes x once per
+        // block instead of twice (the LayerNorm kernels are HBM-bound: 4.7 GB per block instead of 5.1).
+        const void* pend_o = nullptr;     // deltas not yet added to X
+        const void* pend_f = nullptr;
         // Blocks after the deepest tapped hidden state are dead code (Versa configurations tap a prefix of the tower),
         // and in the last LIVE block only the CLS token's output is consumed: K/V are computed for every token, but
-        // attention, O, LN2, FC1, FC2 and the closing residual add run on one row per item (DESIGN.md §4).
+        // attention, O, LN2, FC1, FC2 and the closing residual add run on one row per item (DESIGN.md §4a).
         const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
-            // x (+= FC2 delta of layer l-1) ; h = LN1(x)            -> X is hidden state l
-            IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, L.ln1_w, L.ln1_b, w->eps, pending ? b.X : nullptr, b.H, nullptr, tok, s));
+            // x += pending deltas of block l-1 ; h = LN1(x)            -> X is hidden state l
+            IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
+            pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
             IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
             if (l + 1 < live || g_full_blocks) {
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
-                // x += O delta ; h = LN2(x)
-                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, b.X, b.H, nullptr, tok, s));
+                // h = LN2(x + dO)   (x itself is updated by the next LN1)
+                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, nullptr, tok, s));
                 IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
-                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
-                pending = b.D16;
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16b, D, nullptr, tok, s));
+                pend_o = b.D16;
+                pend_f = b.D16b;
             } else {
                 // CLS rows only; compact [mc, *] views at the front of the (now free) big buffers
                 float* Xc = (float*)b.QKV;      // free once the CLS attention has run (stream order)
@@ -152,7 +160,7 @@ extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* i
         if (g_full_blocks) {
             k = tap_index(tap_layers, n_taps, w->layers);
             if (k >= 0) {
-                IISAN_TRY(launch_add_layernorm768(dt, b.X, pending, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
+                IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
                 IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
             }
         }

@@ -11,6 +11,7 @@ namespace {
 // sum32 <- v (optional, may alias x); out32 / out16 <- LN(v) (optional, out32 may alias x).  g == nullptr: add only.
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const typename T::elem* __restrict__ delta,
+                                                           const typename T::elem* __restrict__ delta2,
                                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                            float* sum32, typename T::elem* __restrict__ out16,
                                                            float* out32, int64_t rows) {
@@ -25,6 +26,11 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
         v[i] = *(const f4*)(xr + i * 256 + lane * 4);
         if (delta) {
             const typename T::v4 d = *(const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
+        }
+        if (delta2) {       // added AFTER delta, in fp32: (x + delta) + delta2 — the same value as two passes produce
+            const typename T::v4 d = *(const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
         }
@@ -168,16 +174,21 @@ __global__ void cast16_kernel(const float* __restrict__ src, typename T::elem* _
 
 }  // namespace
 
-int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
-                            float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
+int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, const void* delta16b, const float* g,
+                             const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
     if (rows <= 0) return IISAN_OK;
     dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
     if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, (const __bf16*)delta16, g, b, eps, sum32, (__bf16*)out16, out32, rows);
+        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, sum32, (__bf16*)out16, out32, rows);
     else
-        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, (const _Float16*)delta16, g, b, eps, sum32, (_Float16*)out16, out32, rows);
+        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, sum32, (_Float16*)out16, out32, rows);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
+}
+
+int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
+                            float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
+    return launch_add2_layernorm768(dtype16, x, delta16, nullptr, g, b, eps, sum32, out16, out32, rows, s);
 }
 
 int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
