@@ -32,6 +32,22 @@ def _need_cuda(*ts):
             raise _lib.IisanHipError("IISAN HIP ops need CUDA/ROCm tensors (got a CPU tensor); there is no CPU path")
 
 
+# When True (set by trainer.FlatTrainer around its backward), the backward kernels accumulate parameter gradients
+# STRAIGHT into `param.grad` (views of the trainer's flat gradient buffer) and the autograd Functions return None for
+# the parameters: no temporary gradient buffers and no per-parameter AccumulateGrad add kernels (146 tiny launches per
+# step).  Must stay False under torch DDP, whose reducer is driven by the AccumulateGrad hooks this bypasses.
+DIRECT_PARAM_GRADS = False
+
+
+def _grad_targets(params: Sequence[torch.Tensor]):
+    """(views to hand to the kernel, what backward returns for the parameters)."""
+    if DIRECT_PARAM_GRADS and all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+                                  for p in params):
+        return [p.grad for p in params], (None,) * len(params)
+    _, views = _flat_grads(params)
+    return views, tuple(views)
+
+
 def _flat_grads(params: Sequence[torch.Tensor]) -> (torch.Tensor, List[torch.Tensor]):
     """One zeroed flat buffer with a view per parameter (the kernels accumulate with +=)."""
     total = sum(p.numel() for p in params)
@@ -123,6 +139,7 @@ class SideNetFn(torch.autograd.Function):
         lib = _lib.load()
         _need_cuda(taps_cv, taps_text, *params)
         taps_cv, taps_text = _f32c(taps_cv), _f32c(taps_text)
+        ctx.orig = list(params)
         params = [_f32c(p.detach()) for p in params]
         M = taps_cv.shape[0]
         need = lib.iisan_side_net_num_params(C.byref(cfg))
@@ -144,12 +161,12 @@ class SideNetFn(torch.autograd.Function):
         taps_cv, taps_text = ctx.saved_tensors
         cfg, params = ctx.cfg, ctx.params
         d_item3 = _f32c(d_item3)
-        _, views = _flat_grads(params)
+        views, ret = _grad_targets(ctx.orig)
         _lib.check(lib.iisan_side_net_bwd(C.byref(cfg), taps_cv.data_ptr(), taps_text.data_ptr(), taps_cv.shape[0],
                                           _ptr_table(params), d_item3.data_ptr(), _ptr_table(views), ctx.ws.data_ptr(),
                                           ctx.ws.numel(), _stream()), "iisan_side_net_bwd")
         ctx.ws = None
-        return (None, None, None) + tuple(views)
+        return (None, None, None) + ret
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -162,6 +179,7 @@ class LinearFn(torch.autograd.Function):
         lib = _lib.load()
         _need_cuda(x, w, b)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
+        ctx.orig = [w, b]
         w, b = _f32c(w.detach()), _f32c(b.detach())
         y = torch.empty((x2.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
         _lib.check(lib.iisan_linear_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), x2.shape[0],
@@ -177,12 +195,11 @@ class LinearFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = _f32c(dy).reshape(-1, w.shape[0])
         dx = torch.empty_like(x2) if ctx.need_dx else None
-        dw = torch.zeros_like(w)
-        db = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+        (dw, db), ret = _grad_targets(ctx.orig)
         _lib.check(lib.iisan_linear_bwd(x2.data_ptr(), w.data_ptr(), dy2.data_ptr(), dx.data_ptr() if dx is not None else None,
                                         dw.data_ptr(), db.data_ptr(), x2.shape[0], w.shape[1], w.shape[0], _stream()),
                    "iisan_linear_bwd")
-        return (dx.view(ctx.in_shape) if dx is not None else None), dw, db
+        return ((dx.view(ctx.in_shape) if dx is not None else None),) + ret
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -214,6 +231,7 @@ class SasrecFn(torch.autograd.Function):
         lib = _lib.load()
         _need_cuda(x, log_mask, *params)
         x, log_mask = _f32c(x), _f32c(log_mask)
+        ctx.orig = list(params)
         params = [_f32c(p.detach()) for p in params]
         B = x.shape[0]
         assert x.shape[1] == cfg.seq and x.shape[2] == cfg.emb, (x.shape, cfg.seq, cfg.emb)
@@ -232,12 +250,12 @@ class SasrecFn(torch.autograd.Function):
         cfg, params = ctx.cfg, ctx.params
         dy = _f32c(dy)
         dx = torch.empty_like(x)
-        _, views = _flat_grads(params)
+        views, ret = _grad_targets(ctx.orig)
         _lib.check(lib.iisan_sasrec_bwd(C.byref(cfg), x.data_ptr(), log_mask.data_ptr(), x.shape[0], _ptr_table(params),
                                         dy.data_ptr(), dx.data_ptr(), _ptr_table(views), ctx.ws.data_ptr(), ctx.ws.numel(),
                                         _stream()), "iisan_sasrec_bwd")
         ctx.ws = None
-        return (None, dx, None) + tuple(views)
+        return (None, dx, None) + ret
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -116,7 +116,11 @@ class FlatTrainer:
     def step(self, ids, images, text, log_mask) -> torch.Tensor:
         self.grad.zero_()                                       # optimizer.zero_grad(), run.py:408
         loss = self.model(ids, images, text, log_mask, None)    # run.py:410
-        loss.backward()                                         # run.py:412
+        prev, ops.DIRECT_PARAM_GRADS = ops.DIRECT_PARAM_GRADS, True    # kernels accumulate straight into self.grad
+        try:
+            loss.backward()                                     # run.py:412
+        finally:
+            ops.DIRECT_PARAM_GRADS = prev
         if self.world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)    # the ONE data-path collective (DDP grad average)
         self.step_no += 1
