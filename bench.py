@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type of the frozen encoders")
     ap.add_argument("--chunk", type=int, default=0, help="items per encoder chunk (0 = whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dedup", action="store_true",
+                    help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
+                         "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
     ap.add_argument("--full-blocks", action="store_true",
                     help="ablation: run every encoder block on every token like HF does (default: the last block computes "
                          "attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed; same taps)")
@@ -107,7 +110,7 @@ def main():
     lib.iisan_set_full_blocks(1 if a.full_blocks else 0)
 
     args = helpers.make_args()
-    batch = synth.scientific_batch(bs=a.bs, seed=12345 + rank, device=dev, images_on_device=True)
+    batch = synth.scientific_batch(bs=a.bs, seed=12345 + rank, device=dev, images_on_device=True, images_by_item=a.dedup)
     vit_w, bert_w = weights.make_vit_weights(), weights.make_bert_weights()
     model = helpers.build_model(args, synth.SCI_ITEM_NUM, batch.pop_prob.cpu(), vit_w, weights.VIT_BASE, bert_w,
                                 weights.BERT_BASE, cached=False, device=dev)
@@ -116,6 +119,7 @@ def main():
     model.mm_encoder.bert_encoder.text_encoders["title"].dtype16 = dt
     model.mm_encoder.cv_encoder.chunk_items = a.chunk
     model.mm_encoder.bert_encoder.text_encoders["title"].chunk_items = a.chunk
+    model.dedup_items = a.dedup
     model.train()
     tr = trainer.FlatTrainer(model, args, world)
     tr.broadcast_params()
@@ -156,7 +160,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "Code_Uncached IISAN ViT-base+BERT-base, Amazon-Scientific-shaped synthetic batch, "
-                                   f"bs={a.bs}/GPU ({slots} item slots, all encoded), 1xMI355X per rank",
+                                   f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        "encoder_blocks": "all tokens in every block (as HF)" if a.full_blocks else
                                          "last block: K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},

@@ -81,21 +81,26 @@ def make_text(ids_flat: np.ndarray, words: int, vocab: int, rs: np.random.Random
     return text
 
 
-def make_images(ids_flat: np.ndarray, res: int, device="cpu", seed: int = 0) -> torch.Tensor:
+def make_images(ids_flat: np.ndarray, res: int, device="cpu", seed: int = 0, by_item: bool = False) -> torch.Tensor:
     """N(0,1) clipped to [-1,1] pixels, zeros on padding slots.  Drawn with a torch generator on `device`
-    (CPU draws are reproducible across machines; device draws are for benchmarks only)."""
+    (CPU draws are reproducible across machines; device draws are for benchmarks only).
+    `by_item`: every occurrence of an item id gets the same picture, as in the real dataset (the image is looked up
+    by id, `dataset.py:73-78`); the default draws one per slot (the golden fixtures were generated that way)."""
     M = ids_flat.shape[0]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     img = torch.randn((M, 3, res, res), generator=g, device=device, dtype=torch.float32).clamp_(-1.0, 1.0)
     real = torch.from_numpy((ids_flat != 0)).to(device)
     img *= real.view(M, 1, 1, 1).to(torch.float32)
+    if by_item:
+        _, first, inverse = np.unique(ids_flat, return_index=True, return_inverse=True)
+        img = img.index_select(0, torch.from_numpy(first[inverse]).to(device))
     return img
 
 
 def scientific_batch(bs: int, seed: int = 12345, seq_len: int = 10, item_num: int = SCI_ITEM_NUM, res: int = 224,
                      words: int = 30, vocab: int = 30522, device="cpu", images_on_device: bool = False,
-                     lengths=None, dup_items: bool = False) -> Batch:
+                     lengths=None, dup_items: bool = False, images_by_item: bool = False) -> Batch:
     rs = np.random.RandomState(seed)
     ids, log_mask = make_ids(bs, seq_len, item_num, rs, lengths)
     if dup_items and bs >= 2:
@@ -103,7 +108,7 @@ def scientific_batch(bs: int, seed: int = 12345, seq_len: int = 10, item_num: in
         ids[1, -1] = ids[0, -2]
     flat = ids.reshape(-1)
     text = make_text(flat, words, vocab, rs)
-    images = make_images(flat, res, device=device if images_on_device else "cpu", seed=seed)
+    images = make_images(flat, res, device=device if images_on_device else "cpu", seed=seed, by_item=images_by_item)
     b = Batch(torch.from_numpy(ids), torch.from_numpy(log_mask), images, torch.from_numpy(text),
               make_pop_prob(item_num))
     return b.to(device)

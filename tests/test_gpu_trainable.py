@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 import golden_io as gio  # noqa: E402
 import helpers  # noqa: E402
-from iisan_amd import _lib, ops, trainer  # noqa: E402
+from iisan_amd import _lib, ops, synth, trainer, weights  # noqa: E402
 from oracle import iisan_oracle as O  # noqa: E402
 
 
@@ -296,3 +296,30 @@ def test_tap_cache_feeds_the_cached_path_identically():
     assert torch.equal(cv_u, cv_c) and torch.equal(tx_u, tx_c) and torch.equal(mm_u, mm_c)
     tbl = evaluate.item_table(ca, taps_cv, taps_tx, batch=10)
     assert tbl.shape == (33, 64) and torch.isfinite(tbl).all()
+
+
+def test_unique_item_encoding_gives_the_same_loss_and_gradients():
+    """with `model.dedup_items = True` every distinct item id of the batch (padding = id 0 included) goes
+    through the frozen encoders once and its taps are scattered back.  On inputs that are a function of the item id —
+    what the reference's datasets produce — loss and every gradient are bit-identical to encoding all slots."""
+    vw, bw = weights.make_vit_weights(gio.E2E_VIT, seed=11), weights.make_bert_weights(gio.E2E_BERT, seed=12)
+    b = synth.scientific_batch(bs=6, seed=77, lengths=[3, 11, 6, 4, 11, 2], res=32, words=8, vocab=512, item_num=14,
+                               images_by_item=True).to("cuda")
+    ids = b.ids.view(-1)
+    assert ids.unique().numel() < (ids != 0).sum().item()          # repeats among the real items, plus padding
+    P = weights.make_trainable_params(seed=101, n_side=3)
+    args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8, drop_rate=0.0)
+    out = []
+    for dedup in (False, True):
+        m = helpers.build_model(args, 14, b.pop_prob.cpu(), vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+        helpers.load_trainables(m, P)
+        m.dedup_items = dedup
+        m.train()
+        loss = m(ids, b.images, b.text, b.log_mask, None)
+        loss.backward()
+        out.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = out
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 50
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
