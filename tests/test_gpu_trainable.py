@@ -301,7 +301,8 @@ def test_tap_cache_feeds_the_cached_path_identically():
 def test_unique_item_encoding_gives_the_same_loss_and_gradients():
     """with `model.dedup_items = True` every distinct item id of the batch (padding = id 0 included) goes
     through the frozen encoders once and its taps are scattered back.  On inputs that are a function of the item id —
-    what the reference's datasets produce — loss and every gradient are bit-identical to encoding all slots."""
+    what the reference's datasets produce — the loss is bit-identical to encoding all slots and the gradients equal up to the
+    summation order of the atomics in the backward kernels."""
     vw, bw = weights.make_vit_weights(gio.E2E_VIT, seed=11), weights.make_bert_weights(gio.E2E_BERT, seed=12)
     b = synth.scientific_batch(bs=6, seed=77, lengths=[3, 11, 6, 4, 11, 2], res=32, words=8, vocab=512, item_num=14,
                                images_by_item=True).to("cuda")
@@ -321,5 +322,5 @@ def test_unique_item_encoding_gives_the_same_loss_and_gradients():
     (l0, g0), (l1, g1) = out
     assert torch.equal(l0, l1)
     assert g0.keys() == g1.keys() and len(g0) > 50
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
+    for k in g0:       # the backward kernels reduce with atomics (gate gradients, split-K dW): equal up to summation order
+        assert torch.allclose(g0[k], g1[k], rtol=1e-4, atol=1e-7), (k, (g0[k] - g1[k]).abs().max().item())
