@@ -42,10 +42,69 @@ def parse():
     ap.add_argument("--dedup", action="store_true",
                     help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
                          "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
+    ap.add_argument("--cached", choices=["fp32", "fp16", "bf16"], default=None,
+                    help="secondary workload (BASELINE config 3, never the headline): Code_Cached IISAN fed from a "
+                         "device-resident packed tap store of the given precision; use with --bs 1024")
     ap.add_argument("--full-blocks", action="store_true",
                     help="ablation: run every encoder block on every token like HF does (default: the last block computes "
                          "attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed; same taps)")
     return ap.parse_args()
+
+
+def bench_cached(a, args, lib, dev, rank, world):
+    """BASELINE config 3: Cached IISAN (side network + SASRec + in-batch CE + Adam, fwd+bwd) on taps gathered on the
+    device from a packed store.  HBM-bound: algorithmic bytes 43,008 B per item slot (7 layers x 2
+    modalities x 768 fp32)."""
+    import helpers
+    from iisan_amd import synth, tapstore, trainer
+    n = synth.SCI_ITEM_NUM
+    ids_np, log_mask = synth.make_ids(a.bs, 10, n, __import__("numpy").random.RandomState(12345 + rank))
+    ids = torch.from_numpy(ids_np).view(-1).to(dev)
+    log_mask = torch.from_numpy(log_mask).to(dev)
+    model = helpers.build_model(args, n, synth.make_pop_prob(n), cached=True, device=dev)
+    layers = list(model.mm_encoder.side_cv_adapter_num_list)
+    g = torch.Generator().manual_seed(1)
+    mk = lambda: tapstore.TapStore(torch.randn(n + 1, len(layers), 768, generator=g) * 0.25, range(len(layers)), dev, a.cached)
+    model.tap_stores = (mk(), mk())
+    model.train()
+    tr = trainer.FlatTrainer(model, args, world)
+    tr.broadcast_params()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = tr.step(ids, None, None, log_mask)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(ids, None, None, log_mask)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        slots = a.bs * 11
+        value = slots * world * a.steps / elapsed
+        alg = 43008.0
+        print(json.dumps({
+            "metric": "items/s (fwd+bwd) Code_Cached IISAN, packed device tap store, Scientific-shaped", "value": value,
+            "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Code_Cached IISAN, bs={a.bs}/GPU ({slots} item slots), tap store {a.cached} "
+                                   f"[{n + 1},{len(layers)},768] x2 = {2 * model.tap_stores[0].nbytes() / 1e6:.0f} MB in HBM",
+                       "loss": float(loss.item())},
+            "roofline": {"bound": "hbm", "achieved": value / world * alg / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": value / world * alg / 8.0e12, "traffic": None,
+                         "note": "whole step against the algorithmic 43,008 B/slot of SURVEY 8d (tap reads only)"},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline(seed=5, budget_s=30.0):
@@ -110,6 +169,8 @@ def main():
     lib.iisan_set_full_blocks(1 if a.full_blocks else 0)
 
     args = helpers.make_args()
+    if a.cached:
+        return bench_cached(a, args, lib, dev, rank, world)
     batch = synth.scientific_batch(bs=a.bs, seed=12345 + rank, device=dev, images_on_device=True, images_by_item=a.dedup)
     vit_w, bert_w = weights.make_vit_weights(), weights.make_bert_weights()
     model = helpers.build_model(args, synth.SCI_ITEM_NUM, batch.pop_prob.cpu(), vit_w, weights.VIT_BASE, bert_w,

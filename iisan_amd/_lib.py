@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiisan_hip.so")
 
-IISAN_F16, IISAN_BF16 = 0, 1
+IISAN_F16, IISAN_BF16, IISAN_F32 = 0, 1, 2
 MAX_LAYERS, MAX_SIDE = 48, 16
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -75,6 +75,7 @@ SIGNATURES = {
     "iisan_attention_cls16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_set_full_blocks": (None, [i32]),
     "iisan_gemm32": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp]),
+    "iisan_gather_taps": (i32, [i32, vp, i64, vp, vp, i64, i64, vp]),
     "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
 }
 

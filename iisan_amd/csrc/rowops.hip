@@ -236,6 +236,54 @@ extern "C" int iisan_layernorm768(int32_t dtype16, const float* x, const float* 
     return launch_layernorm768(dtype16, x, g, b, eps, out16, out32, rows, (hipStream_t)stream);
 }
 
+// ---- packed tap store gather: out[m, :] = fp32(table[ids[m], :]), rows of `row_elems` (multiple of 8) ----
+// one thread = 8 consecutive elements (16-B loads from a 16-bit store, 2x16-B from an fp32 one; two 16-B stores)
+template <typename TS>
+__global__ __launch_bounds__(256) void gather_taps_kernel(const TS* __restrict__ table, const int64_t* __restrict__ ids,
+                                                          float* __restrict__ out, int64_t M, int64_t row_elems, int64_t rows) {
+    const int64_t per_row = row_elems / 8;
+    const int64_t total = M * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / per_row, c = (i - m * per_row) * 8;
+        int64_t id = ids[m];
+        id = id < 0 ? 0 : (id >= rows ? rows - 1 : id);
+        const TS* src = table + id * row_elems + c;
+        f4 lo, hi;
+        if constexpr (sizeof(TS) == 4) {
+            lo = *(const f4*)src;
+            hi = *(const f4*)(src + 4);
+        } else {
+            typedef TS V8 __attribute__((ext_vector_type(8)));
+            const V8 v = *(const V8*)src;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = (float)v[e]; hi[e] = (float)v[4 + e]; }
+        }
+        *(f4*)(out + m * row_elems + c) = lo;
+        *(f4*)(out + m * row_elems + c + 4) = hi;
+    }
+}
+
+extern "C" int iisan_gather_taps(int32_t store_dtype, const void* table, int64_t rows, const int64_t* ids, float* out,
+                                 int64_t M, int64_t row_elems, void* stream) {
+    if (M <= 0) return IISAN_OK;
+    IISAN_CHECK_SHAPE(row_elems > 0 && row_elems % 8 == 0 && rows > 0, "gather_taps: row length %lld must be a positive multiple of 8", (long long)row_elems);
+    const int64_t total = M * (row_elems / 8);
+    const unsigned grid = (unsigned)(ceil_div(total, 256) < 262144 ? ceil_div(total, 256) : 262144);
+    hipStream_t s = (hipStream_t)stream;
+    if (store_dtype == IISAN_F32)
+        hipLaunchKernelGGL(gather_taps_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)table, ids, out, M, row_elems, rows);
+    else if (store_dtype == IISAN_BF16)
+        hipLaunchKernelGGL(gather_taps_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)table, ids, out, M, row_elems, rows);
+    else if (store_dtype == IISAN_F16)
+        hipLaunchKernelGGL(gather_taps_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)table, ids, out, M, row_elems, rows);
+    else {
+        iisan_set_error("gather_taps: unknown store dtype %d", store_dtype);
+        return IISAN_EBADSHAPE;
+    }
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
 extern "C" int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_t n, void* stream) {
     if (n <= 0) return IISAN_OK;
     const unsigned grid = (unsigned)(ceil_div(n, 256) < 65536 ? ceil_div(n, 256) : 65536);

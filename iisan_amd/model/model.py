@@ -120,6 +120,13 @@ class CachedIISANAdaptedMModel(_SideNetBase):
     def forward(self, sample_items_images, sample_items_text):
         return self.forward_item3(sample_items_images, sample_items_text)[1]
 
+    def forward_item3_packed(self, taps_cv_sel, taps_text_sel):
+        """Taps that hold ONLY the layers this side network reads, in its order (`iisan_amd.tapstore.TapStore.gather`):
+        [M, n_side, 768] per modality instead of the reference's [.., 13, 768]."""
+        n = len(self.side_cv_adapter_num_list)
+        assert taps_cv_sel.shape[1] == n and taps_text_sel.shape[1] == n, (taps_cv_sel.shape, taps_text_sel.shape, n)
+        return self._side(taps_cv_sel.contiguous(), taps_text_sel.contiguous(), list(range(n)), 0)
+
 
 class ModelMM(nn.Module):                          # model.py:14-105
     def __init__(self, args, item_num, use_modal, image_net, bert_model, pop_prob_list):
@@ -142,10 +149,16 @@ class ModelMM(nn.Module):                          # model.py:14-105
         # opt-in (not reference behaviour): encode each distinct item id of a batch once (padding = id 0), see
         # IISANAdaptedMModel.forward_item3.  Requires inputs that are a function of the id, as the datasets produce.
         self.dedup_items = False
+        # Cached path only: packed device tap stores (iisan_amd.tapstore.TapStore) for image / text taps.
+        # When set, forward() ignores the `sample_items_images/text` arguments and gathers the taps by item id.
+        self.tap_stores = None
 
     def score_embs(self, sample_items_images, sample_items_text, sample_items_id=None):
         enc = self.mm_encoder
-        if hasattr(enc, "forward_item3"):
+        if self.tap_stores is not None and getattr(enc, "cached", False) and sample_items_id is not None:
+            st_cv, st_tx = self.tap_stores
+            item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id))
+        elif hasattr(enc, "forward_item3"):
             if self.dedup_items and sample_items_id is not None and not getattr(enc, "cached", False):
                 item3, _ = enc.forward_item3(sample_items_images, sample_items_text, sample_items_id)
             else:

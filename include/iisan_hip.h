@@ -35,6 +35,7 @@ extern "C" {
 
 #define IISAN_F16 0
 #define IISAN_BF16 1
+#define IISAN_F32 2   /* storage type of a packed tap store only (iisan_gather_taps) */
 
 #define IISAN_MAX_LAYERS 48
 #define IISAN_MAX_SIDE 16
@@ -233,6 +234,12 @@ int iisan_attention_cls16(int32_t dtype16, const void* qkv, const float* key_bia
  * accumulate != 0: C += (atomic, split-K capable) */
 int iisan_gemm32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
                  int32_t ta, int32_t tb, int32_t relu, int32_t accumulate, void* stream);
+/* Packed device-resident tap store (replaces the 22 `torch.load` calls per sample of
+ * Code_Cached/data_utils/dataset.py:29-34,77-90): table [rows, row_elems] in fp32 / fp16 / bf16 (store_dtype), row i =
+ * the selected CLS taps of item i flattened ([n_sel, D]); out[m, :] = fp32(table[ids[m], :]).  ids int64 on device,
+ * clamped to [0, rows); row_elems must be a multiple of 8. */
+int iisan_gather_taps(int32_t store_dtype, const void* table, int64_t rows, const int64_t* ids, float* out, int64_t M,
+                      int64_t row_elems, void* stream);
 /* f32 -> 16-bit conversion helper used when packing weights */
 int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_t n, void* stream);
 

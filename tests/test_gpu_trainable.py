@@ -324,3 +324,42 @@ def test_unique_item_encoding_gives_the_same_loss_and_gradients():
     assert g0.keys() == g1.keys() and len(g0) > 50
     for k in g0:       # the backward kernels reduce with atomics (gate gradients, split-K dW): equal up to summation order
         assert torch.allclose(g0[k], g1[k], rtol=1e-4, atol=1e-7), (k, (g0[k] - g1[k]).abs().max().item())
+
+
+@pytest.mark.parametrize("store", ["fp32", "fp16", "bf16"])
+def test_packed_tap_store_feeds_the_cached_model(store):
+    """the device-resident packed tap store + on-device gather replaces the per-item host loads of
+    Code_Cached/data_utils/dataset.py:77-90.  fp32 store: loss and gradients equal the reference-layout
+    ([bs,11,13,768]) Cached path; 16-bit stores: equal to that path fed with the correspondingly rounded taps."""
+    from iisan_amd import tapstore
+    item_num, bs = 50, 6
+    args = helpers.make_args(drop_rate=0.0)           # two forward passes must see the same (absent) dropout masks
+    b = synth.scientific_batch(bs=bs, seed=5, item_num=item_num, res=8, words=4, vocab=64)
+    ids = b.ids.view(-1).cuda()
+    cat_ids = torch.arange(item_num + 1)
+    cache_cv = synth.cached_taps(cat_ids, 12, 768, seed=1)          # [item_num+1, 13, 768], row 0 = zeros (padding)
+    cache_tx = synth.cached_taps(cat_ids, 12, 768, seed=2)
+    P = weights.make_trainable_params(seed=99, cached=True)
+    m = helpers.build_model(args, item_num, b.pop_prob, cached=True)
+    helpers.load_trainables(m, P)
+    layers = list(m.mm_encoder.side_cv_adapter_num_list)
+    st_cv = tapstore.TapStore(cache_cv, layers, "cuda", store)
+    st_tx = tapstore.TapStore(cache_tx, layers, "cuda", store)
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[store]
+    g = st_cv.gather(ids)
+    assert torch.equal(g.cpu(), cache_cv[:, layers].to(tdt).float()[ids.cpu()])
+    # reference layout input: [bs, 11, 13, 768] with the same rounding applied
+    full_cv = cache_cv.to(tdt).float()[ids.cpu()].view(bs, 11, 13, 768).cuda()
+    full_tx = cache_tx.to(tdt).float()[ids.cpu()].view(bs, 11, 13, 768).cuda()
+    m.train()
+    l_ref = m(ids, full_cv, full_tx, b.log_mask.cuda(), None)
+    l_ref.backward()
+    g_ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    m.tap_stores = (st_cv, st_tx)
+    l_st = m(ids, None, None, b.log_mask.cuda(), None)
+    l_st.backward()
+    assert torch.equal(l_ref, l_st)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(p.grad, g_ref[k], rtol=1e-4, atol=1e-7), k
