@@ -6,63 +6,76 @@
 //   C[M,N] (=|+=) epilogue( op(A)[M,K] · op(B)[K,N] )
 //   op(A): A stored [M,K] (default) or [K,M] (G32_TA)       op(B): B stored [N,K] (default, torch Linear.weight)
 //                                                                     or [K,N] (G32_TB)
-// 64x64x16 tile per 256-thread workgroup (4 waves, 32x32 each = 2x2 MFMA fragments); operands staged through LDS
-// (17-float rows) with 16-byte global loads; up to 4 independent problems per launch (blockIdx.z) so the cv / text /
-// mm towers of the side network go out together; split-K (blockIdx.y) with fp32 atomics for the weight-gradient
-// products whose M,N are tiny and K = number of item slots.
+// 64x64x64 tile per 256-thread workgroup (4 waves, 32x32 each = 2x2 MFMA fragments); operands go HBM -> registers
+// (16-byte loads) -> LDS (66-float rows: conflict-free fragment reads), and the registers of K-tile t+1 are filled
+// while tile t is multiplied (the first version loaded a 16-wide K slice, synchronised, multiplied, synchronised: 48
+// exposed HBM latencies for K = 768 — 80 us for a 1.1-GFLOP product, rocprofv3); up to 4 independent problems per launch
+// (blockIdx.z) so the cv / text / mm towers of the side network go out together; split-K (blockIdx.y) with fp32
+// atomics for the weight-gradient products whose M,N are tiny and K = number of item slots.
 #include "common.h"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 16, LD = 17;
+constexpr int TM = 64, TN = 64, TK = 64, LD = 66;
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 struct Gemm32Batch {
     Gemm32Prob p[4];
 };
 
-// stage a 64 x 16 operand tile into LDS as S[row][k].  `trans`: source stored [K, rows] (row index contiguous).
-__device__ __forceinline__ void stage_tile(float (*S)[LD], const float* __restrict__ src, int ld, bool trans,
-                                           int64_t row0, int64_t rows, int64_t k0, int64_t kend, int tid) {
-    if (!trans) {
-        const int r = tid >> 2, kc = (tid & 3) * 4;
-        const int64_t row = row0 + r, k = k0 + kc;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < rows) {
-            const float* p = src + row * ld + k;
-            if (k + 3 < kend && (((uintptr_t)p) & 15) == 0) {
-                v = *(const f4*)p;
-            } else {
+// A 64 x 64 operand tile travels as 4 x float4 per thread.  Source stored [rows, K] (default): thread -> row
+// (tid>>4)+16i, k (tid&15)*4; `trans` (source stored [K, rows], row index contiguous): k (tid>>4)+16i, rows (tid&15)*4..
+__device__ __forceinline__ void load_tile(f4 (&v)[4], const float* __restrict__ src, int ld, bool trans, int64_t row0,
+                                          int64_t rows, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e < kend) v[e] = p[e];
+    for (int i = 0; i < 4; ++i) {
+        v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (!trans) {
+            const int64_t row = row0 + (tid >> 4) + 16 * i, k = k0 + (tid & 15) * 4;
+            if (row < rows && k < kend) {
+                const float* p = src + row * ld + k;
+                if (k + 3 < kend && (((uintptr_t)p) & 15) == 0) {
+                    v[i] = *(const f4*)p;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) v[i][e] = p[e];
+                }
+            }
+        } else {
+            const int64_t k = k0 + (tid >> 4) + 16 * i, row = row0 + (tid & 15) * 4;
+            if (k < kend && row < rows) {
+                const float* p = src + k * ld + row;
+                if (row + 3 < rows && (((uintptr_t)p) & 15) == 0) {
+                    v[i] = *(const f4*)p;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < rows) v[i][e] = p[e];
+                }
             }
         }
+    }
+}
+__device__ __forceinline__ void store_tile(float (*S)[LD], const f4 (&v)[4], bool trans, int tid) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[r][kc + e] = v[e];
-    } else {
-        const int kk = tid >> 4, rc = (tid & 15) * 4;
-        const int64_t k = k0 + kk, row = row0 + rc;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kend) {
-            const float* p = src + k * ld + row;
-            if (row + 3 < rows && (((uintptr_t)p) & 15) == 0) {
-                v = *(const f4*)p;
-            } else {
+    for (int i = 0; i < 4; ++i) {
+        if (!trans) {
+            float* d = &S[(tid >> 4) + 16 * i][(tid & 15) * 4];         // 8-byte aligned (row stride 264 B)
+            *(f2v*)d = (f2v){v[i][0], v[i][1]};
+            *(f2v*)(d + 2) = (f2v){v[i][2], v[i][3]};
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (row + e < rows) v[e] = p[e];
-            }
+            for (int e = 0; e < 4; ++e) S[(tid & 15) * 4 + e][(tid >> 4) + 16 * i] = v[i][e];
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) S[rc + e][kk] = v[e];
     }
 }
 
 // structural flags (operand layouts, atomic accumulate) are compile time; epilogue flags are run time
 template <int FLAGS>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
-    __shared__ float As[TM][LD];
-    __shared__ float Bs[TN][LD];
+    __shared__ __attribute__((aligned(16))) float As[TM][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TN][LD];
     const Gemm32Prob& p = batch.p[blockIdx.z];
     const int tiles_n = (p.N + TN - 1) / TN;
     const int64_t tiles_m = (p.M + TM - 1) / TM;
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fi = lane & 15, fk = lane >> 4;
+    constexpr bool TA = (FLAGS & G32_TA) != 0, TB = (FLAGS & G32_TB) != 0;
 
     f4 acc[2][2];
 #pragma unroll
@@ -90,12 +104,19 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    f4 ra[4], rb[4];
+    load_tile(ra, p.A, p.lda, TA, m0, p.M, kbeg, kend, tid);
+    load_tile(rb, p.B, p.ldb, TB, n0, p.N, kbeg, kend, tid);
     for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
-        stage_tile(As, p.A, p.lda, (FLAGS & G32_TA) != 0, m0, p.M, k0, kend, tid);
-        stage_tile(Bs, p.B, p.ldb, (FLAGS & G32_TB) != 0, n0, p.N, k0, kend, tid);
+        store_tile(As, ra, TA, tid);
+        store_tile(Bs, rb, TB, tid);
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        if (k0 + TK < kend) {           // next K-tile: in flight during this tile's MFMAs
+            load_tile(ra, p.A, p.lda, TA, m0, p.M, k0 + TK, kend, tid);
+            load_tile(rb, p.B, p.ldb, TB, n0, p.N, k0 + TK, kend, tid);
+        }
+        const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
+        for (int ks = 0; ks < ksteps; ++ks) {
             float a[2], b[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -186,7 +207,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     int splitk = 1;
     if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
         const int64_t want = ceil_div(1024, max_tiles * nprob);
-        const int64_t maxs = ceil_div(min_k, 4 * TK);
+        const int64_t maxs = ceil_div(min_k, 2 * TK);
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (splitk < 1) splitk = 1;
     }
