@@ -53,6 +53,7 @@ SIGNATURES = {
     "iisan_last_error": (C.c_char_p, []),
     "iisan_vit_forward_taps_ws_bytes": (sz, [C.POINTER(VitWeights), i64, i64]),
     "iisan_vit_forward_taps": (i32, [C.POINTER(VitWeights), vp, i64, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
+    "iisan_vit_forward_taps_u8": (i32, [C.POINTER(VitWeights), vp, i64, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_bert_forward_taps_ws_bytes": (sz, [C.POINTER(BertWeights), i64, i32, i64]),
     "iisan_bert_forward_taps": (i32, [C.POINTER(BertWeights), vp, i64, i32, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_side_net_ws_bytes": (sz, [C.POINTER(SideCfg), i64]),

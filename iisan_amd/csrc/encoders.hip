@@ -5,7 +5,7 @@
 // Code_Cached/preprocess_vectors.py:68-112 precomputes.
 #include "common.h"
 
-int launch_vit_im2col(int dtype16, const float* img, void* out, int64_t M, int C, int R, int p, hipStream_t s);
+int launch_vit_im2col(int dtype16, const void* img, int img_u8, void* out, int64_t M, int C, int R, int p, hipStream_t s);
 int launch_vit_cls_rows(float* X, const float* cls, const float* pos, int64_t M, int T, int D, hipStream_t s);
 int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, const float* pos, const float* type0,
                          const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
@@ -85,9 +85,26 @@ extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, in
     return carve(c, b, Mc * (P + 1), w->hidden, w->mlp > pd ? w->mlp : pd, 0);
 }
 
+static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images, int img_u8, int64_t M,
+                                 const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* images, int64_t M,
                                       const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
                                       void* ws, size_t ws_bytes, void* stream) {
+    return vit_forward_taps_impl(w, images, 0, M, tap_layers, n_taps, taps, chunk_items, ws, ws_bytes, stream);
+}
+
+extern "C" int iisan_vit_forward_taps_u8(const iisan_vit_weights* w, const uint8_t* images, int64_t M,
+                                         const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    IISAN_CHECK_SHAPE(w->image % 8 == 0, "vit u8: image side %d must be a multiple of 8", w->image);
+    return vit_forward_taps_impl(w, images, 1, M, tap_layers, n_taps, taps, chunk_items, ws, ws_bytes, stream);
+}
+
+static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images, int img_u8, int64_t M,
+                                 const int32_t* tap_layers, int32_t n_taps, float* taps, int64_t chunk_items,
+                                 void* ws, size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     IISAN_CHECK_SHAPE(M > 0, "vit_forward_taps: M must be positive");
     IISAN_TRY(check_common(w->hidden, w->layers, w->heads, w->mlp, n_taps, tap_layers));
@@ -110,7 +127,9 @@ extern "C" int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* i
         const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;
         const int64_t tok = mc * T;
         float* tp = taps + m0 * n_taps * D;
-        IISAN_TRY(launch_vit_im2col(dt, images + m0 * img_elems, b.F1, mc, w->channels, w->image, w->patch, s));
+        const void* img0 = img_u8 ? (const void*)((const uint8_t*)images + m0 * img_elems)
+                                  : (const void*)((const float*)images + m0 * img_elems);
+        IISAN_TRY(launch_vit_im2col(dt, img0, img_u8, b.F1, mc, w->channels, w->image, w->patch, s));
         IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));
         IISAN_TRY(launch_vit_cls_rows(b.X, w->cls_token, w->pos_emb, mc, T, D, s));
         int k = tap_index(tap_layers, n_taps, 0);

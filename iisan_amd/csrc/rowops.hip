@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
 
 // ---- ViT patch extraction: images fp32 [M,C,R,R] -> patch matrix 16-bit [M*P, C*p*p], col = c*p*p + iy*p + ix ----
 // one thread = 8 consecutive ix (two float4 reads, one 16-byte store)
-template <typename T>
-__global__ __launch_bounds__(256) void vit_im2col_kernel(const float* __restrict__ img, typename T::elem* __restrict__ out,
+// SRC = float: already normalised pixels; SRC = uint8_t: raw pixels, normalised here exactly as the reference's
+// transform does in fp32 — ToTensor (x/255) then Normalize(mean .5, std .5) (`Code_Uncached/data_utils/dataset.py:46-50`)
+// — so the 16-bit patch matrix is bit-identical to the fp32 route while the image crosses PCIe/HBM at a quarter the size.
+template <typename T, typename SRC>
+__global__ __launch_bounds__(256) void vit_im2col_kernel(const SRC* __restrict__ img, typename T::elem* __restrict__ out,
                                                          int64_t M, int C, int R, int p) {
     const int per_row = C * p * p / 8;        // threads per patch row
     const int gp = R / p;                      // patches per image side
@@ -80,8 +83,20 @@ __global__ __launch_bounds__(256) void vit_im2col_kernel(const float* __restrict
         const int c = col / (p * p), rem = col % (p * p), iy = rem / p, ix = rem % p;
         const int64_t m = pr / (gp * gp);
         const int pp = (int)(pr % (gp * gp)), py = pp / gp, px = pp % gp;
-        const float* src = img + ((m * C + c) * R + (py * p + iy)) * (int64_t)R + px * p + ix;
-        const f4 a = *(const f4*)src, b2 = *(const f4*)(src + 4);
+        const SRC* src = img + ((m * C + c) * R + (py * p + iy)) * (int64_t)R + px * p + ix;
+        f4 a, b2;
+        if constexpr (sizeof(SRC) == 4) {
+            a = *(const f4*)src;
+            b2 = *(const f4*)(src + 4);
+        } else {
+            typedef uint8_t U8 __attribute__((ext_vector_type(8)));
+            const U8 u = *(const U8*)src;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = __fdiv_rn(__fdiv_rn((float)u[e], 255.0f) - 0.5f, 0.5f);
+                b2[e] = __fdiv_rn(__fdiv_rn((float)u[4 + e], 255.0f) - 0.5f, 0.5f);
+            }
+        }
         typename T::v8 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -196,13 +211,20 @@ int launch_layernorm768(int dtype16, const float* x, const float* g, const float
     return launch_add_layernorm768(dtype16, x, nullptr, g, b, eps, nullptr, out16, out32, rows, s);
 }
 
-int launch_vit_im2col(int dtype16, const float* img, void* out, int64_t M, int C, int R, int p, hipStream_t s) {
+int launch_vit_im2col(int dtype16, const void* img, int img_u8, void* out, int64_t M, int C, int R, int p, hipStream_t s) {
     const int64_t total = M * (R / p) * (R / p) * (C * p * p / 8);
     const unsigned grid = (unsigned)(ceil_div(total, 256) < 262144 ? ceil_div(total, 256) : 262144);
-    if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(vit_im2col_kernel<BF16>, dim3(grid), dim3(256), 0, s, img, (__bf16*)out, M, C, R, p);
-    else
-        hipLaunchKernelGGL(vit_im2col_kernel<F16>, dim3(grid), dim3(256), 0, s, img, (_Float16*)out, M, C, R, p);
+    if (img_u8) {
+        if (dtype16 == IISAN_BF16)
+            hipLaunchKernelGGL((vit_im2col_kernel<BF16, uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (__bf16*)out, M, C, R, p);
+        else
+            hipLaunchKernelGGL((vit_im2col_kernel<F16, uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (_Float16*)out, M, C, R, p);
+    } else {
+        if (dtype16 == IISAN_BF16)
+            hipLaunchKernelGGL((vit_im2col_kernel<BF16, float>), dim3(grid), dim3(256), 0, s, (const float*)img, (__bf16*)out, M, C, R, p);
+        else
+            hipLaunchKernelGGL((vit_im2col_kernel<F16, float>), dim3(grid), dim3(256), 0, s, (const float*)img, (_Float16*)out, M, C, R, p);
+    }
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

@@ -84,18 +84,20 @@ class PackedVit(_PackedEncoder):
         self._w = None
 
     def forward_taps(self, images: torch.Tensor, tap_layers: Sequence[int], chunk_items: int = 0) -> torch.Tensor:
-        """images fp32 [M,C,R,R] -> fp32 [M, len(tap_layers), D] (`encoders.py:29-31` + `model.py:212`)."""
+        """images fp32 [M,C,R,R] (normalised) or uint8 [M,C,R,R] (raw pixels, normalised on the device) -> fp32
+        [M, len(tap_layers), D] (`encoders.py:29-31` + `model.py:212`)."""
         lib = _lib.load()
         cfg = self.cfg
-        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert images.is_cuda and images.dtype in (torch.float32, torch.uint8) and images.is_contiguous()
         assert images.shape[1:] == (cfg.channels, cfg.image, cfg.image), images.shape
         M = images.shape[0]
         taps = torch.empty((M, len(tap_layers), cfg.hidden), dtype=torch.float32, device=images.device)
         tl = (C.c_int32 * len(tap_layers))(*tap_layers)
         nbytes = lib.iisan_vit_forward_taps_ws_bytes(C.byref(self.struct), M, chunk_items)
         ws = self.ws.get(nbytes, images.device)
-        _lib.check(lib.iisan_vit_forward_taps(C.byref(self.struct), _ptr(images), M, tl, len(tap_layers), _ptr(taps),
-                                              chunk_items, _ptr(ws), ws.numel(), _stream()), "iisan_vit_forward_taps")
+        fn = lib.iisan_vit_forward_taps_u8 if images.dtype == torch.uint8 else lib.iisan_vit_forward_taps
+        _lib.check(fn(C.byref(self.struct), _ptr(images), M, tl, len(tap_layers), _ptr(taps),
+                      chunk_items, _ptr(ws), ws.numel(), _stream()), "iisan_vit_forward_taps")
         return taps
 
 

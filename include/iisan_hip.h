@@ -89,6 +89,12 @@ size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, in
 int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* images, int64_t M,
                            const int32_t* tap_layers, int32_t n_taps, float* taps,
                            int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
+/* The same from RAW uint8 pixels [M,C,R,R] (0..255): ToTensor + Normalize(.5,.5) of the reference's transform
+ * (Code_Uncached/data_utils/dataset.py:46-50) are applied in fp32 inside the patch-extraction kernel — taps identical to
+ * the fp32 entry point fed with the normalised image, a quarter of the input bytes. */
+int iisan_vit_forward_taps_u8(const iisan_vit_weights* w, const uint8_t* images, int64_t M,
+                              const int32_t* tap_layers, int32_t n_taps, float* taps,
+                              int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
 
 /* Replaces Text_Encoder/Bert_Encoder.forward + tap selection (encoders.py:81-91,148-159, model.py:211,213):
  * text int64 [M, 2W] (W ids then W attention-mask values) -> taps fp32 [M, n_taps, D]. */

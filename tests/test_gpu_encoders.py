@@ -86,3 +86,16 @@ def test_cls_only_last_block_matches_full_blocks(lib):
     assert _rel(sc[:, 2], fc[:, 4]) < 5e-4 and _rel(st[:, 2], ft[:, 4]) < 5e-4
     ref_c, ref_t = torch.from_numpy(z["taps_cv"]), torch.from_numpy(z["taps_text"])
     assert _rel(sc[:, 2], ref_c[:, 4]) < TAP_TOL[_lib.IISAN_F16] and _rel(st[:, 2], ref_t[:, 4]) < TAP_TOL[_lib.IISAN_F16]
+
+
+def test_uint8_images_give_the_same_taps_as_normalised_fp32():
+    """raw uint8 pixels normalised inside the patch-extraction kernel (ToTensor + Normalize(.5,.5) in fp32,
+    Code_Uncached/data_utils/dataset.py:46-50) == the fp32 entry point fed with the host-normalised image, bit for bit."""
+    vw = weights.make_vit_weights(gio.E2E_VIT, seed=11)
+    vit = encoders.PackedVit(vw, gio.E2E_VIT, "cuda")
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, 3, 32, 32), generator=g, dtype=torch.uint8)
+    ref = (u8.float().div(255) - 0.5) / 0.5            # torchvision ToTensor + Normalize
+    t_u8 = vit.forward_taps(u8.cuda(), [0, 1, 2]).cpu()
+    t_f32 = vit.forward_taps(ref.cuda(), [0, 1, 2]).cpu()
+    assert torch.equal(t_u8, t_f32)
