@@ -133,6 +133,52 @@ __device__ __forceinline__ f2 gelu_erf_fast2(f2 x) {
     mx[0] = fmaxf(x[0], 0.f); mx[1] = fmaxf(x[1], 0.f);
     return __builtin_elementwise_fma(ax * -0.5f, r, mx);
 }
+// The same on 8 pairs at once, written step by step across the pairs so that every Horner / squaring step is 8
+// INDEPENDENT instructions: with one wave per SIMD doing VALU work the dependent chain of a single evaluation (6 fma +
+// 4 mul + rcp + fma, ~8 cycles of latency each) is otherwise exposed.
+__device__ __forceinline__ void gelu_erf_fast2x8(f2 (&x)[8]) {
+    f2 ax[8], z[8], p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ax[k][0] = fabsf(x[k][0]); ax[k][1] = fabsf(x[k][1]); z[k] = ax[k] * 0.70710678118654752440f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(z[k], (f2)0.0000430638f, (f2)0.0002765672f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0001520143f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0092705272f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0422820123f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0705230784f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)1.0f);
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = p[k] * p[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f2 r, mx;
+        r[0] = __builtin_amdgcn_rcpf(p[k][0]); r[1] = __builtin_amdgcn_rcpf(p[k][1]);
+        mx[0] = fmaxf(x[k][0], 0.f); mx[1] = fmaxf(x[k][1], 0.f);
+        x[k] = __builtin_elementwise_fma(ax[k] * -0.5f, r, mx);
+    }
+}
+// scalar twin of gelu_erf_fast2 (same formula, plain v_fma_f32): kept for A/B timing — packed fp32 VALU next to MFMAs can
+// be slower than two plain instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+__device__ __forceinline__ float gelu_erf_fast1(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    float p = fmaf(z, 0.0000430638f, 0.0002765672f);
+    p = fmaf(p, z, 0.0001520143f);
+    p = fmaf(p, z, 0.0092705272f);
+    p = fmaf(p, z, 0.0422820123f);
+    p = fmaf(p, z, 0.0705230784f);
+    p = fmaf(p, z, 1.0f);
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const float r = __builtin_amdgcn_rcpf(p);
+    return fmaf(ax * -0.5f, r, fmaxf(x, 0.f));
+}
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

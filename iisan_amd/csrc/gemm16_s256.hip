@@ -267,15 +267,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
                 } else {
                     op = (typename T::elem*)p.out + m * p.ldo + n;
                 }
+                f2 g[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = (f2){v[2 * k], v[2 * k + 1]};
+                if constexpr (EPI == EPI_GELU16) gelu_erf_fast2x8(g);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     V8 o;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        f2 g = {v[8 * h2 + e], v[8 * h2 + e + 1]};
-                        if constexpr (EPI == EPI_GELU16) g = gelu_erf_fast2(g);
-                        o[e] = T::from_f32(g[0]);
-                        o[e + 1] = T::from_f32(g[1]);
+                        o[e] = T::from_f32(g[4 * h2 + e / 2][0]);
+                        o[e + 1] = T::from_f32(g[4 * h2 + e / 2][1]);
                     }
                     *(V8*)(op + 8 * h2) = o;
                 }
