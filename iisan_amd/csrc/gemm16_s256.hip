@@ -392,6 +392,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     if (dbg_on && lane == 0)
         for (int i = 0; i < 1024; ++i) ((unsigned*)p.out)[8192 + grp * 1024 + i] = sStamp[i];
 #endif
+    // The plan is unconditional, so the last MFMA slots issued LDS-DMA loads nobody reads: they must have landed before
+    // this workgroup's LDS can be handed to another workgroup.
+    S256_VMCNT(0);
     if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
         ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
         ((long long*)p.out)[2 * blockIdx.x + 1] = nsteps;
