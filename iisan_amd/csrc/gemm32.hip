@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 64, LD = 66;
+constexpr int TN = 64, TK = 64, LD = 66;
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 struct Gemm32Batch {
@@ -25,10 +25,12 @@ struct Gemm32Batch {
 
 // A 64 x 64 operand tile travels as 4 x float4 per thread.  Source stored [rows, K] (default): thread -> row
 // (tid>>4)+16i, k (tid&15)*4; `trans` (source stored [K, rows], row index contiguous): k (tid>>4)+16i, rows (tid&15)*4..
-__device__ __forceinline__ void load_tile(f4 (&v)[4], const float* __restrict__ src, int ld, bool trans, int64_t row0,
+template <int ROWS>
+__device__ __forceinline__ void load_tile(f4 (&v)[ROWS / 16], const float* __restrict__ src, int ld, bool trans, int64_t row0,
                                           int64_t rows, int64_t k0, int64_t kend, int tid) {
+    constexpr int TPR = ROWS / 4;                // trans: threads per K-row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 16; ++i) {
         v[i] = (f4){0.f, 0.f, 0.f, 0.f};
         if (!trans) {
             const int64_t row = row0 + (tid >> 4) + 16 * i, k = k0 + (tid & 15) * 4;
@@ -43,7 +45,7 @@ __device__ __forceinline__ void load_tile(f4 (&v)[4], const float* __restrict__ 
                 }
             }
         } else {
-            const int64_t k = k0 + (tid >> 4) + 16 * i, row = row0 + (tid & 15) * 4;
+            const int64_t k = k0 + tid / TPR + (256 / TPR) * i, row = row0 + (tid % TPR) * 4;
             if (k < kend && row < rows) {
                 const float* p = src + k * ld + row;
                 if (row + 3 < rows && (((uintptr_t)p) & 15) == 0) {
@@ -57,23 +59,31 @@ __device__ __forceinline__ void load_tile(f4 (&v)[4], const float* __restrict__ 
         }
     }
 }
-__device__ __forceinline__ void store_tile(float (*S)[LD], const f4 (&v)[4], bool trans, int tid) {
+template <int ROWS>
+__device__ __forceinline__ void store_tile(float (*S)[LD], const f4 (&v)[ROWS / 16], bool trans, int tid) {
+    constexpr int TPR = ROWS / 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 16; ++i) {
         if (!trans) {
             float* d = &S[(tid >> 4) + 16 * i][(tid & 15) * 4];         // 8-byte aligned (row stride 264 B)
             *(f2v*)d = (f2v){v[i][0], v[i][1]};
             *(f2v*)(d + 2) = (f2v){v[i][2], v[i][3]};
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) S[(tid & 15) * 4 + e][(tid >> 4) + 16 * i] = v[i][e];
+            for (int e = 0; e < 4; ++e) S[(tid % TPR) * 4 + e][tid / TPR + (256 / TPR) * i] = v[i][e];
         }
     }
 }
 
 // structural flags (operand layouts, atomic accumulate) are compile time; epilogue flags are run time
-template <int FLAGS>
+// TMV = rows of the output tile (64 / 32 / 16).  A wave's MFMA chain is (TMV x 64 x K) / 4 waves long at 32 cycles per
+// 16x16x4 step: the skinny products of the side network ([M,768] -> 64: one column tile, K = 768) took 40 us with 64-row
+// tiles whatever M was (tools/gemm32_time.py) — 22 workgroups at M = 1408, each a 12-us dependent MFMA chain plus LDS
+// traffic — so tiles shrink until the launch fills the chip.
+template <int FLAGS, int TMV>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
+    constexpr int TM = TMV;
+    constexpr int WM = TMV >= 32 ? 2 : 1, WN = 4 / WM, FM = TMV / 16 / WM, FN = 4 / WN;
     __shared__ __attribute__((aligned(16))) float As[TM][LD];
     __shared__ __attribute__((aligned(16))) float Bs[TN][LD];
     const Gemm32Prob& p = batch.p[blockIdx.z];
@@ -94,57 +104,81 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     if (kbeg >= kend && blockIdx.y > 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fi = lane & 15, fk = lane >> 4;
     constexpr bool TA = (FLAGS & G32_TA) != 0, TB = (FLAGS & G32_TB) != 0;
 
-    f4 acc[2][2];
+    // KA independent accumulator sets over alternating K-slices: with one fragment per wave every MFMA would wait for
+    // the previous one (same accumulator, ~40 cycles each)
+    constexpr int KA = (FM * FN >= 4) ? 1 : 4 / (FM * FN);
+    f4 acc[KA][FM][FN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < KA; ++q)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b) acc[q][a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    f4 ra[4], rb[4];
-    load_tile(ra, p.A, p.lda, TA, m0, p.M, kbeg, kend, tid);
-    load_tile(rb, p.B, p.ldb, TB, n0, p.N, kbeg, kend, tid);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
-        store_tile(As, ra, TA, tid);
-        store_tile(Bs, rb, TB, tid);
-        __syncthreads();
-        if (k0 + TK < kend) {           // next K-tile: in flight during this tile's MFMAs
-            load_tile(ra, p.A, p.lda, TA, m0, p.M, k0 + TK, kend, tid);
-            load_tile(rb, p.B, p.ldb, TB, n0, p.N, k0 + TK, kend, tid);
+    // Three K-tiles in flight (register ring, statically indexed by unrolling x3): the products are tiny (one K-tile is
+    // 64 MFMAs, ~0.3 us) and an HBM/L2 round trip is 1-2 us, so with one tile of look-ahead every iteration still
+    // waited for most of a round trip.
+    constexpr int DEPTH = 3;
+    f4 ra[DEPTH][TM / 16], rb[DEPTH][4];
+    auto fetch = [&](int slot, int64_t k) {
+        if (k < kend) {
+            load_tile<TM>(ra[slot], p.A, p.lda, TA, m0, p.M, k, kend, tid);
+            load_tile<TN>(rb[slot], p.B, p.ldb, TB, n0, p.N, k, kend, tid);
         }
-        const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
-        for (int ks = 0; ks < ksteps; ++ks) {
-            float a[2], b[2];
+    };
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                a[f] = As[wm * 32 + f * 16 + fi][ks * 4 + fk];
-                b[f] = Bs[wn * 32 + f * 16 + fi][ks * 4 + fk];
+    for (int u = 0; u < DEPTH; ++u) fetch(u, kbeg + (int64_t)u * TK);
+    for (int64_t kb = kbeg; kb < kend; kb += (int64_t)DEPTH * TK) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int64_t k0 = kb + (int64_t)u * TK;
+            if (k0 < kend) {                          // wave-uniform
+                store_tile<TM>(As, ra[u], TA, tid);
+                store_tile<TN>(Bs, rb[u], TB, tid);
+                __syncthreads();
+                fetch(u, k0 + (int64_t)DEPTH * TK);
+                const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
+                for (int ks0 = 0; ks0 < ksteps; ks0 += KA) {
+#pragma unroll
+                    for (int q = 0; q < KA; ++q) {
+                        const int ks = ks0 + q;               // rows beyond the tail are zero-filled: harmless
+                        float a[FM], b[FN];
+#pragma unroll
+                        for (int f = 0; f < FM; ++f) a[f] = As[wm * 16 * FM + f * 16 + fi][ks * 4 + fk];
+#pragma unroll
+                        for (int f = 0; f < FN; ++f) b[f] = Bs[wn * 16 * FN + f * 16 + fi][ks * 4 + fk];
+#pragma unroll
+                        for (int mf = 0; mf < FM; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < FN; ++nf)
+                                acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
             }
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
         }
-        __syncthreads();
     }
 
     const bool first_split = blockIdx.y == 0;
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < FM; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            const int n = n0 + wn * 32 + nf * 16 + fi;
+        for (int nf = 0; nf < FN; ++nf) {
+            const int n = n0 + wn * 16 * FN + nf * 16 + fi;
             if (n >= p.N) continue;
             const float bias = (p.bias && first_split) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm * 32 + mf * 16 + fk * 4 + r;
+                const int64_t m = m0 + wm * 16 * FM + mf * 16 + fk * 4 + r;
                 if (m >= p.M) continue;
-                float v = acc[mf][nf][r] + bias;
+                float v = acc[0][mf][nf][r];
+#pragma unroll
+                for (int q = 1; q < KA; ++q) v += acc[q][mf][nf][r];
+                v += bias;
                 if (epi & G32_PREACT) ((float*)p.act_src)[m * p.ldc + n] = v;
                 if (epi & G32_RELU) v = fmaxf(v, 0.f);
                 if (epi & G32_GELU) v = gelu_erf(v);
@@ -184,8 +218,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
 }
 
 template <int FLAGS>
-int launch_flags(const Gemm32Batch& b, dim3 grid, int epi, hipStream_t s) {
-    hipLaunchKernelGGL(gemm32_kernel<FLAGS>, grid, dim3(256), 0, s, b, epi);
+int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, hipStream_t s) {
+    if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64>), grid, dim3(256), 0, s, b, epi);
+    else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32>), grid, dim3(256), 0, s, b, epi);
+    else hipLaunchKernelGGL((gemm32_kernel<FLAGS, 16>), grid, dim3(256), 0, s, b, epi);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
@@ -195,14 +231,27 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int epi, hipStream_t s) {
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
     IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
     Gemm32Batch b{};
-    int64_t max_tiles = 0, min_k = INT64_MAX;
+    int64_t min_k = INT64_MAX;
     for (int i = 0; i < nprob; ++i) {
         b.p[i] = probs[i];
         IISAN_CHECK_SHAPE(probs[i].M > 0 && probs[i].N > 0 && probs[i].K > 0, "gemm32: empty problem %d", i);
-        const int64_t t = ceil_div(probs[i].M, TM) * ceil_div(probs[i].N, TN);
-        if (t > max_tiles) max_tiles = t;
         if (probs[i].K < min_k) min_k = probs[i].K;
     }
+    auto tiles_for = [&](int tm) {
+        int64_t mt = 0;
+        for (int i = 0; i < nprob; ++i) {
+            const int64_t t = ceil_div(probs[i].M, tm) * ceil_div(probs[i].N, TN);
+            if (t > mt) mt = t;
+        }
+        return mt;
+    };
+    // row-tile height: the tallest that still gives the chip ~one workgroup per CU (weight-gradient launches spread
+    // K instead and keep 64)
+    int TM = 64;
+    if (!(flags & G32_ACCUM)) {
+        if (tiles_for(64) * nprob < 192) TM = tiles_for(32) * nprob >= 192 ? 32 : 16;
+    }
+    const int64_t max_tiles = tiles_for(TM);
     IISAN_CHECK_SHAPE(max_tiles < (1ll << 31), "gemm32: grid too large");
     int splitk = 1;
     if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
@@ -215,7 +264,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
     const int epi = flags & ~structural;
     switch (structural) {
-#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, epi, s)
+#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, s)
         G32_CASE(0);
         G32_CASE(G32_TA);
         G32_CASE(G32_TB);
