@@ -99,3 +99,44 @@ def test_uint8_images_give_the_same_taps_as_normalised_fp32():
     t_u8 = vit.forward_taps(u8.cuda(), [0, 1, 2]).cpu()
     t_f32 = vit.forward_taps(ref.cuda(), [0, 1, 2]).cpu()
     assert torch.equal(t_u8, t_f32)
+
+
+@pytest.mark.parametrize("M", [1, 2, 5])
+def test_tiny_and_ragged_batches(M):
+    """Edge cases: a single item, batches far below one GEMM tile, an all-padding item (zero image, zero title and an
+    all-zero attention mask: HF attends uniformly) next to real ones — taps finite and equal to the oracle."""
+    z, vw, bw, b, P = gio.e2e_small_inputs()
+    vit = encoders.PackedVit(vw, gio.E2E_VIT, "cuda")
+    bert = encoders.PackedBert(bw, gio.E2E_BERT, "cuda")
+    ids = b.ids.view(-1)
+    pad = int((ids == 0).nonzero()[0])              # one padding slot first, then real ones
+    real = [int(i) for i in (ids != 0).nonzero().view(-1)[:M - 1]]
+    sel = torch.tensor([pad] + real)[:M]
+    img, txt = b.images[sel].contiguous(), b.text[sel].contiguous()
+    assert img[0].abs().max() == 0 and txt[0].abs().max() == 0
+    with torch.no_grad():
+        oc = O.vit_cls_taps(img, vw, gio.E2E_VIT)
+        ot = O.bert_cls_taps(txt, bw, gio.E2E_BERT)
+    tc = vit.forward_taps(img.cuda(), [0, 1, 2]).cpu()
+    tt = bert.forward_taps(txt.cuda(), [0, 1, 2]).cpu()
+    assert torch.isfinite(tc).all() and torch.isfinite(tt).all()
+    for l in (1, 2):
+        assert _rel(tc[:, l], oc[:, l]) < 1.5e-3, _rel(tc[:, l], oc[:, l])
+        assert _rel(tt[:, l], ot[:, l]) < 1.5e-3, _rel(tt[:, l], ot[:, l])
+    # the same rows inside a larger batch give the same bits (rows are independent, whatever the tile they land in)
+    big_c = vit.forward_taps(b.images.cuda(), [0, 1, 2]).cpu()[sel]
+    big_t = bert.forward_taps(b.text.cuda(), [0, 1, 2]).cpu()[sel]
+    assert torch.equal(big_c, tc) and torch.equal(big_t, tt)
+
+
+def test_bad_arguments_are_reported_not_executed(lib):
+    """Error behaviour of the boundary: negative return code + message, nothing launched."""
+    z, vw, bw, b, P = gio.e2e_small_inputs()
+    vit = encoders.PackedVit(vw, gio.E2E_VIT, "cuda")
+    img = b.images[:2].cuda()
+    with pytest.raises(_lib.IisanHipError):
+        vit.forward_taps(img, [0, 99])                       # tap layer outside the tower
+    with pytest.raises(AssertionError):
+        vit.forward_taps(img[:, :, :16], [0])                # wrong image size
+    with pytest.raises((AssertionError, _lib.IisanHipError)):
+        vit.forward_taps(img.cpu(), [0])                     # no CPU path
