@@ -62,7 +62,7 @@ def bench_cached(a, args, lib, dev, rank, world):
     ids = torch.from_numpy(ids_np).view(-1).to(dev)
     log_mask = torch.from_numpy(log_mask).to(dev)
     model = helpers.build_model(args, n, synth.make_pop_prob(n), cached=True, device=dev)
-    layers = list(model.mm_encoder.side_cv_adapter_num_list)
+    layers = model.mm_encoder.packed_layers()
     g = torch.Generator().manual_seed(1)
     mk = lambda: tapstore.TapStore(torch.randn(n + 1, len(layers), 768, generator=g) * 0.25, range(len(layers)), dev, a.cached)
     model.tap_stores = (mk(), mk())

@@ -120,12 +120,18 @@ class CachedIISANAdaptedMModel(_SideNetBase):
     def forward(self, sample_items_images, sample_items_text):
         return self.forward_item3(sample_items_images, sample_items_text)[1]
 
+    def packed_layers(self):
+        """Layer list a packed `TapStore` must hold for this model (both modalities): the side network's tap list,
+        preceded by layer 0 when `remove_first` (the states are seeded with tap 0, model.py:215-218)."""
+        return ([0] if self.remove_first else []) + list(self.side_cv_adapter_num_list)
+
     def forward_item3_packed(self, taps_cv_sel, taps_text_sel):
-        """Taps that hold ONLY the layers this side network reads, in its order (`iisan_amd.tapstore.TapStore.gather`):
-        [M, n_side, 768] per modality instead of the reference's [.., 13, 768]."""
+        """Taps that hold ONLY the layers this side network reads, in `packed_layers()` order
+        (`iisan_amd.tapstore.TapStore.gather`): [M, n, 768] per modality instead of the reference's [.., 13, 768]."""
+        o = 1 if self.remove_first else 0
         n = len(self.side_cv_adapter_num_list)
-        assert taps_cv_sel.shape[1] == n and taps_text_sel.shape[1] == n, (taps_cv_sel.shape, taps_text_sel.shape, n)
-        return self._side(taps_cv_sel.contiguous(), taps_text_sel.contiguous(), list(range(n)), 0)
+        assert taps_cv_sel.shape[1] == n + o and taps_text_sel.shape[1] == n + o, (taps_cv_sel.shape, taps_text_sel.shape, n)
+        return self._side(taps_cv_sel.contiguous(), taps_text_sel.contiguous(), list(range(o, n + o)), 0)
 
 
 class ModelMM(nn.Module):                          # model.py:14-105

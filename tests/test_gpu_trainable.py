@@ -342,7 +342,7 @@ def test_packed_tap_store_feeds_the_cached_model(store):
     P = weights.make_trainable_params(seed=99, cached=True)
     m = helpers.build_model(args, item_num, b.pop_prob, cached=True)
     helpers.load_trainables(m, P)
-    layers = list(m.mm_encoder.side_cv_adapter_num_list)
+    layers = m.mm_encoder.packed_layers()
     st_cv = tapstore.TapStore(cache_cv, layers, "cuda", store)
     st_tx = tapstore.TapStore(cache_tx, layers, "cuda", store)
     tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[store]
@@ -363,3 +363,37 @@ def test_packed_tap_store_feeds_the_cached_model(store):
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert torch.allclose(p.grad, g_ref[k], rtol=1e-4, atol=1e-7), k
+
+
+@pytest.mark.parametrize("variant", ["text_wide_long", "equal_rmfirst"])
+def test_versa_packed_tap_store(variant):
+    """Versa with the packed device tap store (asymmetric towers: a store per modality holding only that tower's
+    layers): loss equal to the reference-layout forward of the same model."""
+    from iisan_amd import tapstore
+    z, b, taps_cv, taps_tx, args, model, P = gio.versa_inputs(variant, device="cuda")
+    args.drop_rate = 0.0
+    helpers.load_trainables(model, P)
+    model.eval()
+    bs, S = b.log_mask.shape
+    ids = b.ids.view(-1).cuda()
+    tc = taps_cv.view(bs, S + 1, taps_cv.shape[1], -1).cuda()
+    tt = taps_tx.view(bs, S + 1, taps_tx.shape[1], -1).cuda()
+    l_ref = model(ids, tc, tt, b.log_mask.cuda(), 0)
+    # a catalogue in which item id i carries the taps of the slot it occupies in this batch (ids repeat consistently:
+    # duplicated ids get one of their slots' taps in BOTH paths, so rebuild the reference-layout input from the store)
+    n_items = int(ids.max()) + 1
+    cat_cv = torch.zeros(n_items, *taps_cv.shape[1:])
+    cat_tx = torch.zeros(n_items, *taps_tx.shape[1:])
+    cat_cv[ids.cpu()] = taps_cv
+    cat_tx[ids.cpu()] = taps_tx
+    enc = model.mm_encoder
+    lay_cv, lay_tx = enc.packed_layers()
+    st_cv = tapstore.TapStore(cat_cv, lay_cv, "cuda", "fp32", zero_padding_row=False)
+    st_tx = tapstore.TapStore(cat_tx, lay_tx, "cuda", "fp32", zero_padding_row=False)
+    tc2 = cat_cv[ids.cpu()].view_as(tc.cpu()).cuda()
+    tt2 = cat_tx[ids.cpu()].view_as(tt.cpu()).cuda()
+    l_ref2 = model(ids, tc2, tt2, b.log_mask.cuda(), 0)
+    model.tap_stores = (st_cv, st_tx)
+    l_st = model(ids, None, None, b.log_mask.cuda(), 0)
+    assert torch.equal(l_ref2, l_st)
+    assert torch.isfinite(l_ref) and torch.isfinite(l_st)
