@@ -397,3 +397,44 @@ def test_versa_packed_tap_store(variant):
     l_st = model(ids, None, None, b.log_mask.cuda(), 0)
     assert torch.equal(l_ref2, l_st)
     assert torch.isfinite(l_ref) and torch.isfinite(l_st)
+
+
+def test_versa_at_baseline_config5_widths_matches_oracle():
+    """BASELINE config 5 shapes: image taps [M, 25, 1024] (ViT-L), text taps [M, 81, 8192] (Llama-3-70B token means),
+    tap lists of Code_Cached_Asym/script/run_IISAN.py (6 text / 6 image layers + layer 0), dim-align 8192 -> 1024.
+    No golden at this size (58 MB of taps per modality for 22 slots): HIP forward/backward against the CPU oracle, which
+    is itself pinned to the reference on the small Versa fixtures."""
+    Di, Dt, Lc, Lt = 1024, 8192, 25, 81
+    vlist, blist = "3,7,11,15,19,23", "4,19,34,49,64,79"
+    b = synth.scientific_batch(bs=2, seed=78, lengths=[5, 11], dup_items=False, res=16, item_num=50)
+    taps_cv = synth.cached_taps(b.ids, Lc - 1, Di, seed=15)
+    taps_tx = synth.cached_taps(b.ids, Lt - 1, Dt, seed=16)
+    args = helpers.make_args(text_embedding_dim=Dt, image_embedding_dim=Di, side_adapter_vit_list=vlist,
+                             side_adapter_bert_list=blist, image_layers=Lc - 1, text_layers=Lt - 1, drop_rate=0.0)
+    model = helpers.build_model(args, 50, b.pop_prob, cached="versa", device="cuda")
+    shapes = {n: tuple(p.shape) for n, p in model.named_parameters() if p.requires_grad}
+    P = weights.fill_params_seeded(shapes, seed=555)
+    helpers.load_trainables(model, P)
+    model.train()
+    bs, S = b.log_mask.shape
+    tc = taps_cv.view(bs, S + 1, Lc, Di).cuda()
+    tt = taps_tx.view(bs, S + 1, Lt, Dt).cuda()
+    loss = model(b.ids.cuda().view(-1), tc, tt, b.log_mask.cuda(), 0)
+    loss.backward()
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lc, lt = O.side_layer_list(vlist, False), O.side_layer_list(blist, False)
+    cv, text, mm = O.versa_side_network(taps_cv, taps_tx, Po, lc, lt)
+    score = torch.nn.functional.linear(torch.cat([cv, text, mm], 1), Po["com_dense.weight"], Po["com_dense.bias"])
+    prec = O.sasrec(score.view(bs, S + 1, 64)[:, :-1], b.log_mask, Po, 2, 2).reshape(-1, 64)
+    ref = O.inbatch_ce(b.ids, score, prec, b.log_mask, b.pop_prob)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 3e-5 * abs(ref.item()), (loss.item(), ref.item())
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            g, r = p.grad.cpu(), Po[n].grad
+            assert g.shape == r.shape, n
+            err = (g - r).abs().max().item() / (r.abs().max().item() + 1e-12)
+            worst = max(worst, err)
+            assert err < 2e-3, (n, err)
+    assert worst > 0.0
