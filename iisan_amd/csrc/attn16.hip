@@ -138,23 +138,38 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             // VALU diet (PMC: this kernel is VALU-bound, 1088 VALU instructions per 16-query block before): the
             // mask select runs only on tiles that can contain masked/padded keys, scale+subtract is one fma, and
             // exp2 is the bare v_exp_f32 (arguments <= 0, results in [0,1]: no range fix-up needed).
+            // The K fragments of tile t+1 are requested before the MFMAs of tile t (no branch inside this loop: with the
+            // per-tile `if`s of the first version every tile was its own basic block and each pair of MFMAs waited a
+            // full LDS round trip — the ISA showed read, s_waitcnt, mfma, read, s_waitcnt, mfma ... and PMC 49 % of
+            // the wave time in waits).
             f4 sc[NT16];
+            {
+                constexpr int KBATCH = (NT16 % 7 == 0) ? 7 : (NT16 % 4 == 0 ? 4 : NT16);   // tiles whose K fragments are requested together (divides NT16)
 #pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (!(dbg & 2)) {
+                for (int t0 = 0; t0 < NT16; t0 += KBATCH) {
+                    V8 kf[KBATCH][2];
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const V8 kf = *(const V8*)(sK + (t * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
-                        acc = T::mfma(kf, qf[i][kk], acc);
+                    for (int u = 0; u < KBATCH; ++u)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            kf[u][kk] = *(const V8*)(sK + ((t0 + u) * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
+#pragma unroll
+                    for (int u = 0; u < KBATCH; ++u) {
+                        f4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = T::mfma(kf[u][0], qf[i][0], acc);
+                        acc = T::mfma(kf[u][1], qf[i][1], acc);
+                        sc[t0 + u] = acc;
                     }
                 }
-                if (key_bias != nullptr || t * 16 + 16 > S) {        // wave-uniform
+            }
+            // masks afterwards, only on the tiles that can hold masked / padded keys (wave-uniform conditions)
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                if (key_bias != nullptr || t * 16 + 16 > S) {
                     const f4 kb = *(const f4*)(sKB + t * 16 + g * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = kb[r] < -1.5f ? -INFINITY : (kb[r] < 0.f ? MASK_RAW : acc[r]);
+                    for (int r = 0; r < 4; ++r) sc[t][r] = kb[r] < -1.5f ? -INFINITY : (kb[r] < 0.f ? MASK_RAW : sc[t][r]);
                 }
-                sc[t] = acc;
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -181,26 +196,37 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             f4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = (f4){0.f, 0.f, 0.f, 0.f};
+            {
+                auto vload = [&](int kb, V8 (&vf)[4]) {
 #pragma unroll
-            for (int kb = 0; kb < NT16 / 2; ++kb) {
-                if ((dbg & 4) && kb > 0) break;
-                V8 pf;
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const E* vr = sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 4;
+                        const V4 lo = *(const V4*)vr, hi2 = *(const V4*)(vr + 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[e] = T::from_f32(sc[2 * kb][e]);
-                    pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
-                }
+                        for (int e = 0; e < 4; ++e) {
+                            vf[dt][e] = lo[e];
+                            vf[dt][4 + e] = hi2[e];
+                        }
+                    }
+                };
+                V8 vc[4];
+                vload(0, vc);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const E* vr = sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 4;
-                    const V4 lo = *(const V4*)vr, hi2 = *(const V4*)(vr + 16);
-                    V8 vf;
+                for (int kb = 0; kb < NT16 / 2; ++kb) {
+                    V8 vn[4];
+                    if (kb + 1 < NT16 / 2) vload(kb + 1, vn);          // next step's V^T fragments: in flight during the MFMAs
+                    V8 pf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        vf[e] = lo[e];
-                        vf[4 + e] = hi2[e];
+                        pf[e] = T::from_f32(sc[2 * kb][e]);
+                        pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
                     }
-                    o[dt] = T::mfma(vf, pf, o[dt]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = T::mfma(vc[dt], pf, o[dt]);
+                    if (kb + 1 < NT16 / 2) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) vc[dt] = vn[dt];
+                    }
                 }
             }
             if (sq < S && !(dbg & 8)) {
