@@ -438,3 +438,25 @@ def test_versa_at_baseline_config5_widths_matches_oracle():
             worst = max(worst, err)
             assert err < 2e-3, (n, err)
     assert worst > 0.0
+
+
+def test_production_size_step_meets_the_north_star_tolerance():
+    """The north-star tolerance at PRODUCTION size: ViT-B/16 + BERT-base (12 layers each, seeded weights), the default
+    IISAN side network (7 taps per tower), bs = 2 sequences = 22 item slots, fp16 encoder operands, dead-work pruning
+    on — HIP loss within 1e-3 relative of the fp32 CPU oracle's, and the item embeddings of real slots within 1e-3."""
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    b = synth.scientific_batch(bs=2, seed=2024, lengths=[11, 4])
+    args = helpers.make_args(drop_rate=0.0)
+    model = helpers.build_model(args, synth.SCI_ITEM_NUM, b.pop_prob, vw, weights.VIT_BASE, bw, weights.BERT_BASE, cached=False)
+    P = weights.make_trainable_params(seed=99)
+    helpers.load_trainables(model, P)
+    model.train()
+    ids = b.ids.view(-1)
+    loss = model(ids.cuda(), b.images.cuda(), b.text.cuda(), b.log_mask.cuda(), 0)
+    with torch.no_grad():
+        tc = O.vit_cls_taps(b.images, vw, weights.VIT_BASE)
+        tt = O.bert_cls_taps(b.text, bw, weights.BERT_BASE)
+        layers = O.side_layer_list(args.side_adapter_vit_list, False)
+        ref, aux = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, P, layers)
+    rel = abs(loss.item() - ref.item()) / abs(ref.item())
+    assert rel < 1e-3, f"production-size loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e}"
