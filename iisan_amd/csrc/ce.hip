@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int E = 64;
+constexpr int MAXS1 = 16;         // sequences of up to 16 slots keep their ids in registers / LDS (longer ones take the slow loop)
 constexpr int YLD = 68;           // padded LDS row (floats)
 constexpr float MASKV = -1e4f;
 
@@ -95,6 +96,14 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
                                                       float d_loss, float* __restrict__ dX) {
     __shared__ __attribute__((aligned(16))) float sY[4][16 * YLD];
     __shared__ float sRed[4][16][E + 4];
+    // per-wave, per-tile metadata (the first version fetched it from global memory per logit: 3 + S1 loads — and in the
+    // d_score pass 3 more plus two 64-bit divisions — for each of a lane's 4 logits, ~56 load instructions per 16 MFMAs:
+    // the passes ran at 15 TF of the 157 TF f32 MFMA rate at bs=1024).
+    //   FWD / DPREC (row fixed per lane): sMeta = ids | pad flags | debias of the tile's 16 columns.
+    //   DSCORE (column fixed per lane):   sMeta = ids of the <=4 sequences the tile's 16 rows belong to,
+    //                                     sRow  = per row: sequence index in that table | label column | lse | scale.
+    __shared__ __attribute__((aligned(16))) int sMeta[4][64];
+    __shared__ __attribute__((aligned(16))) int sRow[4][64];
     const int S1 = S + 1;
     const int64_t T = bs * S, M = bs * S1;
     const float* X = MODE == CE_DSCORE ? score : prec;
@@ -137,6 +146,20 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
         col_debias = b.debias[xc];
     }
 
+    // FWD / DPREC: this lane's row belongs to one sequence for the whole pass: its ids live in registers
+    const bool fast = S1 <= MAXS1 && S >= 5 && M < (1ll << 31);
+    int rid[MAXS1];
+#pragma unroll
+    for (int p = 0; p < MAXS1; ++p) rid[p] = -1;
+    if (MODE != CE_DSCORE && fast) {
+#pragma unroll
+        for (int p = 0; p < MAXS1; ++p)
+            if (p < S1) rid[p] = b.ids32[row_seq * S1 + p];
+    }
+    int* myMeta = sMeta[wave];
+    int* myRow = sRow[wave];
+    const float dscale = MODE == CE_DSCORE ? d_loss / b.nvalid[0] : 0.f;
+
     float run_m = -INFINITY, run_l = 0.f, zlab = 0.f;
     f4 dacc[4];
 #pragma unroll
@@ -157,7 +180,39 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
                 *(f4*)(myY + r * YLD + ch * 16 + v * 4) = t;
             }
         }
+        unsigned hitmask = 0;                        // DSCORE: bit s = this lane's column id occurs in sequence seq0 + s
+        if (fast) {
+            if (MODE != CE_DSCORE) {                 // columns y0 .. y0+15
+                if (lane < 16) {
+                    const int64_t cc = y0 + lane < NY ? y0 + lane : NY - 1;
+                    myMeta[lane] = b.ids32[cc];
+                    myMeta[16 + lane] = b.colpad[cc];
+                    myMeta[32 + lane] = __float_as_int(b.debias[cc]);
+                }
+            } else {                                 // rows y0 .. y0+15 span at most 4 sequences (S >= 5)
+                const unsigned seq0 = (unsigned)y0 / (unsigned)S;
+                for (int i = lane; i < 4 * S1; i += 64) {
+                    const int64_t sq_ = (int64_t)seq0 + i / S1;
+                    myMeta[i] = sq_ < bs ? b.ids32[sq_ * S1 + (i % S1)] : -1;
+                }
+                if (lane < 16) {
+                    const unsigned rw = (unsigned)(y0 + lane < NY ? y0 + lane : NY - 1);
+                    const unsigned rs = rw / (unsigned)S;
+                    myRow[lane] = (int)(rs - seq0);
+                    myRow[16 + lane] = (int)(rs * (unsigned)S1 + (rw - rs * (unsigned)S) + 1u);
+                    myRow[32 + lane] = __float_as_int(b.lse[rw]);
+                    myRow[48 + lane] = __float_as_int(log_mask[rw] != 0.f ? dscale : 0.f);
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
+        if (fast && MODE == CE_DSCORE) {
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                bool h = false;
+                for (int p = 0; p < S1; ++p) h |= myMeta[sidx * S1 + p] == col_id;       // wave-uniform addresses: LDS broadcast
+                hitmask |= h ? (1u << sidx) : 0u;
+            }
+        }
         // Z^T tile: A = Y rows (i = lane&15), B = X rows
         f4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -176,16 +231,41 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
             int64_t row, col, seq, label;
             int idc, pad;
             float deb;
+            bool hit = false;
+            float r_lse = 0.f, r_scale = 0.f;        // DSCORE fast path: per-row values from the tile table
             if (MODE != CE_DSCORE) {
                 row = xc; col = yc; seq = row_seq; label = row_label;
-                idc = b.ids32[col]; pad = b.colpad[col]; deb = b.debias[col];
+                if (fast) {
+                    const int cl = (int)(yc - y0);
+                    idc = myMeta[cl]; pad = myMeta[16 + cl]; deb = __int_as_float(myMeta[32 + cl]);
+                } else {
+                    idc = b.ids32[col]; pad = b.colpad[col]; deb = b.debias[col];
+                }
             } else {
-                row = yc; col = xc; seq = row / S; label = seq * S1 + (row - seq * S) + 1;
+                row = yc; col = xc;
                 idc = col_id; pad = col_pad; deb = col_debias;
+                if (fast) {
+                    const int rr = (int)(yc - y0);
+                    seq = 0;
+                    label = myRow[16 + rr];
+                    hit = (hitmask >> myRow[rr]) & 1u;
+                    r_lse = __int_as_float(myRow[32 + rr]);
+                    r_scale = __int_as_float(myRow[48 + rr]);
+                } else {
+                    seq = row / S; label = seq * S1 + (row - seq * S) + 1;
+                }
             }
             float val = z[r] - deb;
             if (pad) val = MASKV;
-            else if (col != label && id_in_seq(b.ids32, seq, S1, idc)) val = MASKV;
+            else if (col != label) {
+                if (MODE != CE_DSCORE && fast) {
+#pragma unroll
+                    for (int p = 0; p < MAXS1; ++p) hit |= rid[p] == idc;
+                } else if (!fast) {
+                    hit = id_in_seq(b.ids32, seq, S1, idc);
+                }
+                if (hit) val = MASKV;
+            }
             if (MODE == CE_FWD) {
                 if (yok) {
                     if (val > run_m) {
@@ -200,6 +280,8 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
                 float lse, scale;
                 if (MODE == CE_DPREC) {
                     lse = row_lse; scale = row_scale;
+                } else if (fast) {
+                    lse = r_lse; scale = r_scale;
                 } else {
                     lse = b.lse[row];
                     scale = log_mask[row] != 0.f ? d_loss / b.nvalid[0] : 0.f;
