@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 __syncthreads();
                 fetch(u, k0 + (int64_t)DEPTH * TK);
                 const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
-                for (int ks0 = 0; ks0 < ksteps; ks0 += KA) {
+                auto kstep = [&](int ks0) {
 #pragma unroll
                     for (int q = 0; q < KA; ++q) {
                         const int ks = ks0 + q;               // rows beyond the tail are zero-filled: harmless
@@ -157,6 +157,12 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                             for (int nf = 0; nf < FN; ++nf)
                                 acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
                     }
+                };
+                if (ksteps == TK / 4) {        // full tile: unrolled, so the LDS reads of later slices overlap the MFMAs of earlier ones
+#pragma unroll
+                    for (int ks0 = 0; ks0 < TK / 4; ks0 += KA) kstep(ks0);
+                } else {
+                    for (int ks0 = 0; ks0 < ksteps; ks0 += KA) kstep(ks0);
                 }
                 __syncthreads();
             }
