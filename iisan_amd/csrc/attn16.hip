@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
             const int r = r0 + 32 * p;
-            if (r < S) kreg[p] = *(const V8*)(kb_ + r * 64 + c * 8);
+            // K and V of a head are read by exactly one workgroup, once: non-temporal (634 -> 619 us; nt on the Q loads or
+            // on the context stores made it slower)
+            if (r < S) kreg[p] = __builtin_nontemporal_load((const V8*)(kb_ + r * 64 + c * 8));
             else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) kreg[p][e] = (E)0.f;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = (r0 + 32 * p) * 4 + r;
-                if (key < S) vreg[p][r] = *(const V8*)(vb_ + key * 64 + c * 8);
+                if (key < S) vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + key * 64 + c * 8));
                 else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) vreg[p][r][e] = (E)0.f;

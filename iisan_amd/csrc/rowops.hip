@@ -18,23 +18,25 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // The fp32 residual stream and the 16-bit deltas are read once and not touched again for gigabytes: non-temporal
+    // accesses (measured: 220.7 -> 201.8 us average per launch over a step's 49 launches)
     const float* xr = x + row * 768;
     f4 v[3];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        v[i] = *(const f4*)(xr + i * 256 + lane * 4);
+        v[i] = __builtin_nontemporal_load((const f4*)(xr + i * 256 + lane * 4));
         if (delta) {
-            const typename T::v4 d = *(const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4);
+            const typename T::v4 d = __builtin_nontemporal_load((const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
         }
         if (delta2) {       // added AFTER delta, in fp32: (x + delta) + delta2 — the same value as two passes produce
-            const typename T::v4 d = *(const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4);
+            const typename T::v4 d = __builtin_nontemporal_load((const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
         }
-        if (sum32) *(f4*)(sum32 + row * 768 + i * 256 + lane * 4) = v[i];
+        if (sum32) __builtin_nontemporal_store(v[i], (f4*)(sum32 + row * 768 + i * 256 + lane * 4));
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     if (!g) return;
