@@ -104,6 +104,10 @@ def load():
         raise IisanHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C iisan_amd/csrc`).  There is no CPU fallback for the IISAN hot path.")
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  If this library were loaded before torch the
+    # system runtime it links against would be resident first, and a process that then initialises torch's GPU state on
+    # top of it reports "no ROCm-capable device" (seen with build() followed by smoke() in one interpreter).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is absent: loud by design
