@@ -4,8 +4,8 @@
 // 55 % of the MFMA peak — all 8 waves read their fragments from LDS at the same time and then all issue MFMAs at the
 // same time, so the two waves sharing a SIMD never overlap (LDS-read phase: matrix pipe idle; MFMA phase: LDS idle).
 //
-// Here the workgroup is split into two groups of four waves, A = wave_m 0 (rows 0..127 of the tile) and B = wave_m 1
-// (rows 128..255); waves w and w+4 share a SIMD.  Time is cut into SLOTS separated by one `s_barrier`; each group
+// Here the workgroup is split into two groups of four waves, A (rows 0..127 of the tile; waves 4..7) and B (rows
+// 128..255; waves 0..3); waves w and w+4 share a SIMD.  Time is cut into SLOTS separated by one `s_barrier`; each group
 // alternates a READ slot R(s) (24 ds_read_b128: every fragment of K-step s into registers) and an MFMA slot M(s)
 // (32 x v_mfma_f32_32x32x16), and B runs ONE SLOT BEHIND A:
 //
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;            // 0 = A (tile rows 0..127), 1 = B (rows 128..255)
+    // 0 = A (tile rows 0..127), 1 = B (rows 128..255).  The YOUNGER half of the workgroup (waves 4..7) is group A: on every
+    // SIMD the younger wave loses arbitration to its older sibling, so its MFMA slot runs longer (slot timelines: 1,640 vs
+    // 1,252 cycles with the older waves as A; 1,400 vs 1,276 this way round) — it gets the lighter DMA duty (A-operand
+    // halves; group B streams the W tile that every CU hammers) and the leading position.
+    const int grp = 1 - (wave >> 2);
     const int wq = wave & 3;              // wave within the group = its 64-column slice of the tile
 
     const int G = gridDim.x;
