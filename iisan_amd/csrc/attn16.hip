@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 template <typename T>
 __global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::elem* __restrict__ qkv,
                                                             const float* __restrict__ key_bias,
-                                                            typename T::elem* __restrict__ ctx, int64_t pairs, int S, int heads) {
+                                                            typename T::elem* __restrict__ ctx, int64_t pairs, int S, int heads,
+                                                            const typename T::elem* __restrict__ q_cls) {
     typedef typename T::elem E;
     typedef typename T::v8 V8;
     typedef typename T::v4 V4;
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::el
     float q[64];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const V8 t = *(const V8*)(qb_ + c * 8);
+        // q_cls: the CLS queries come from their own [items, heads*64] projection (the QKV GEMM wrote K and V only)
+        const V8 t = q_cls ? *(const V8*)(q_cls + (item * heads + h) * 64 + c * 8) : *(const V8*)(qb_ + c * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[c * 8 + e] = T::to_f32(t[e]);
     }
@@ -360,14 +362,14 @@ int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void
 }
 
 int launch_attention_cls16(int dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items, int S, int heads,
-                           hipStream_t s) {
+                           hipStream_t s, const void* q_cls) {
     IISAN_CHECK_SHAPE(items > 0 && S > 0 && S <= 256 && heads > 0, "attention_cls16: unsupported problem (S=%d)", S);
     const int64_t pairs = items * heads;
     dim3 grid((unsigned)ceil_div(pairs, 4)), block(256);
     if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(attention_cls_kernel<BF16>, grid, block, 0, s, (const __bf16*)qkv, key_bias, (__bf16*)ctx_cls, pairs, S, heads);
+        hipLaunchKernelGGL(attention_cls_kernel<BF16>, grid, block, 0, s, (const __bf16*)qkv, key_bias, (__bf16*)ctx_cls, pairs, S, heads, (const __bf16*)q_cls);
     else
-        hipLaunchKernelGGL(attention_cls_kernel<F16>, grid, block, 0, s, (const _Float16*)qkv, key_bias, (_Float16*)ctx_cls, pairs, S, heads);
+        hipLaunchKernelGGL(attention_cls_kernel<F16>, grid, block, 0, s, (const _Float16*)qkv, key_bias, (_Float16*)ctx_cls, pairs, S, heads, (const _Float16*)q_cls);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
@@ -379,5 +381,5 @@ extern "C" int iisan_attention16(int32_t dtype16, const void* qkv, const float* 
 
 extern "C" int iisan_attention_cls16(int32_t dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items,
                                      int32_t S, int32_t heads, void* stream) {
-    return launch_attention_cls16(dtype16, qkv, key_bias, ctx_cls, items, S, heads, (hipStream_t)stream);
+    return launch_attention_cls16(dtype16, qkv, key_bias, ctx_cls, items, S, heads, (hipStream_t)stream, nullptr);
 }

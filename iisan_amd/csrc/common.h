@@ -241,6 +241,7 @@ struct Gemm16Args {
     int32_t lda, ldw, ldo;
     int32_t patch_P;    // >0: row remap m -> (m/P)*(P+1) + 1 + m%P, += pos[1 + m%P]
     int32_t qkv_S, qkv_heads;   // EPI_QKVH16: tokens per item and heads of the head-major QKV layout
+    int32_t qkv_which0;         // EPI_QKVH16: first of q|k|v (0..2) the N = (3 - which0)*64*heads columns hold (1 = K and V only)
     int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
 };
 enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4 };
@@ -259,7 +260,7 @@ int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void
                        int heads, hipStream_t s);
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)
 int launch_attention_cls16(int dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items, int S,
-                           int heads, hipStream_t s);
+                           int heads, hipStream_t s, const void* q_cls = nullptr);   // q_cls: [items, heads*64] 16-bit CLS queries
 
 struct Gemm32Prob {
     const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;

@@ -11,6 +11,7 @@ int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, co
                          const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
                          int W, int vocab, hipStream_t s);
 int launch_gather_cls(const float* X, float* taps, int64_t M, int T, int D, int n_taps, int k, hipStream_t s);
+int launch_gather_rows16(const void* H, void* out, int64_t M, int T, int D, hipStream_t s);   // out[m] = H[m*T] (16-bit rows)
 
 namespace {
 
@@ -37,12 +38,24 @@ size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int D, int F, int64_t kb_e
 }
 
 int gemm(int dt, int mode, const void* A, int K, const void* W, const float* bias, void* out, int N, const float* resid,
-         int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0, int qkv_S = 0, int qkv_heads = 0) {
+         int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0, int qkv_S = 0, int qkv_heads = 0,
+         int qkv_which0 = 0) {
     Gemm16Args a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = pos;
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = patch_P;
-    a.qkv_S = qkv_S; a.qkv_heads = qkv_heads;
+    a.qkv_S = qkv_S; a.qkv_heads = qkv_heads; a.qkv_which0 = qkv_which0;
     return launch_gemm16(dt, mode, a, s);
+}
+
+// Last live block: K and V for every token (head-major; the q third of the buffer is left untouched), Q for the CLS rows
+// only.  Hc (in) / Qc (out) are compact [mc, D] 16-bit views: Hc = the CLS rows of the block's 16-bit input H.
+int kv_all_q_cls(int dt, const iisan_layer_weights& L, const void* H, void* QKV, const void* Hc, void* Qc, int64_t tok,
+                 int64_t mc, int T, int heads, int D, hipStream_t s) {
+    const size_t e16 = 2;
+    IISAN_TRY(gemm(dt, EPI_QKVH16, H, D, (const char*)L.qkv_w + (size_t)D * D * e16, L.qkv_b + D, QKV, 2 * D, nullptr, tok, s,
+                   nullptr, 0, T, heads, 1));
+    IISAN_TRY(gemm(dt, EPI_OUT16, Hc, D, L.qkv_w, L.qkv_b, Qc, D, nullptr, mc, s));
+    return IISAN_OK;
 }
 
 int tap_index(const int32_t* tap_layers, int n, int layer) {
@@ -152,8 +165,8 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
             pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
-            IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
             if (l + 1 < live || g_full_blocks) {
+                IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
                 // h = LN2(x + dO)   (x itself is updated by the next LN1)
@@ -163,9 +176,13 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 pend_o = b.D16;
                 pend_f = b.D16b;
             } else {
-                // CLS rows only; compact [mc, *] views at the front of the (now free) big buffers
+                // CLS rows only; compact [mc, *] views at the front of big buffers that are free at this point
+                void* Hc = (char*)b.F1;                                           // 16-bit [mc, D]   (F1 is free until FC1)
+                void* Qc = (char*)b.F1 + (size_t)mc * D * 2;                      // 16-bit [mc, D]
+                IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));            // CLS rows of LN1(x)
+                IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
+                IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s, Qc));
                 float* Xc = (float*)b.QKV;      // free once the CLS attention has run (stream order)
-                IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
                 IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
                 IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln2_w, L.ln2_b, w->eps, Xc, b.H, nullptr, mc, s));
@@ -223,8 +240,8 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // a = LN(x + O(attn(x)))
-            IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
             if (l + 1 < live || g_full_blocks) {
+                IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
                 IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, b.X, tok, s));
@@ -235,8 +252,13 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                 k = tap_index(tap_layers, n_taps, l + 1);
                 if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
             } else {
+                // post-LN tower: the block input H is the 16-bit image of X, so the CLS rows of H are gathered directly
+                void* Hc = (char*)b.F1;                                           // 16-bit [mc, D]   (F1 is free until FC1)
+                void* Qc = (char*)b.F1 + (size_t)mc * D * 2;
+                IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));
+                IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
                 float* Xc = (float*)b.QKV;
-                IISAN_TRY(launch_attention_cls16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
+                IISAN_TRY(launch_attention_cls16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s, Qc));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
                 IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
                 IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, Xc, mc, s));

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                     const int Dm = p.qkv_heads * 64;
                     const int64_t item = m / p.qkv_S;
                     const int tok = (int)(m - item * p.qkv_S);
-                    const int which = n / Dm, hd = (n - which * Dm) >> 6, d = n & 63;
+                    const int wq_ = n / Dm, hd = (n - wq_ * Dm) >> 6, d = n & 63, which = wq_ + p.qkv_which0;
                     *(V8*)((typename T::elem*)p.out + (((item * p.qkv_heads + hd) * 3 + which) * p.qkv_S + tok) * 64 + d) = o;
                 } else {
                     *(V8*)((typename T::elem*)p.out + m * p.ldo + n) = o;
@@ -199,7 +199,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(ceil_div(a.M, BM) * (a.N / BN) < (1ll << 31), "gemm16: grid too large");
     IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
-    IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.N == 3 * 64 * a.qkv_heads),
+    IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.qkv_which0 >= 0 && a.qkv_which0 <= 2 && a.N == (3 - a.qkv_which0) * 64 * a.qkv_heads),
                       "gemm16: head-major QKV mode needs S, heads and N == 3*64*heads");
     const bool timed = iisan_timing_on();
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K);

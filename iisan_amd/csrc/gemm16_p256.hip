@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
                         const int Dm = p.qkv_heads * 64;
                         const int64_t item = m / p.qkv_S;
                         const int tok = (int)(m - item * p.qkv_S);
-                        const int which = n / Dm, hd = (n - which * Dm) >> 6, d = n & 63;
+                        const int wq_ = n / Dm, hd = (n - wq_ * Dm) >> 6, d = n & 63, which = wq_ + p.qkv_which0;
                         op = (typename T::elem*)p.out + (((item * p.qkv_heads + hd) * 3 + which) * p.qkv_S + tok) * 64 + d;
                     } else {
                         op = (typename T::elem*)p.out + m * p.ldo + n;

@@ -240,8 +240,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         const unsigned qk_S = (unsigned)p.qkv_S;
         if constexpr (EPI == EPI_QKVH16) {
             const unsigned Dm = (unsigned)p.qkv_heads * 64u, n64 = (unsigned)(tn * SBN + wq * 64);
-            qk_which = n64 / Dm;
-            qk_hd = (n64 - qk_which * Dm) >> 6;
+            const unsigned wq_ = n64 / Dm;
+            qk_hd = (n64 - wq_ * Dm) >> 6;
+            qk_which = wq_ + (unsigned)p.qkv_which0;
             const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + half * 64 + frow);
             qk_item = m0 / qk_S;
             qk_tok = m0 - qk_item * qk_S;

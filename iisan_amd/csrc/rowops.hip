@@ -183,6 +183,15 @@ __global__ void gather_cls_kernel(const float* __restrict__ X, float* __restrict
     *(f4*)(taps + (m * n_taps + k) * D + c) = *(const f4*)(X + m * T * D + c);
 }
 
+// 16-bit rows: out[m, :] = H[m*T, :]  (CLS rows of a token-major 16-bit activation), 16 bytes per thread
+__global__ void gather_rows16_kernel(const uint4* __restrict__ H, uint4* __restrict__ out, int64_t M, int T, int D8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * D8) return;
+    const int64_t m = i / D8;
+    const int c = (int)(i - m * D8);
+    out[m * D8 + c] = H[m * T * D8 + c];
+}
+
 template <typename T>
 __global__ void cast16_kernel(const float* __restrict__ src, typename T::elem* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -245,6 +254,13 @@ int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, co
         hipLaunchKernelGGL(bert_embed_ln_kernel<BF16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (__bf16*)H, key_bias, M, W, vocab);
     else
         hipLaunchKernelGGL(bert_embed_ln_kernel<F16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (_Float16*)H, key_bias, M, W, vocab);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_gather_rows16(const void* H, void* out, int64_t M, int T, int D, hipStream_t s) {
+    const int D8 = D / 8;
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)ceil_div(M * D8, 256)), dim3(256), 0, s, (const uint4*)H, (uint4*)out, M, T, D8);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
