@@ -127,3 +127,82 @@ class FlatTrainer:
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.seg_end, self.seg_lr, self.step_no,
                       grad_scale=1.0 / self.world)              # run.py:413
         return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Checkpoints in the reference's format (`data_utils/utils.py:104-110`, `run.py:262-277`):
+#   {'model_state_dict', 'optimizer', 'rng_state', 'cuda_rng_state'} with `optimizer` a torch.optim.Adam state dict
+#   over the five run.py groups, so a checkpoint written here resumes under the reference's run.py and vice versa.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _segments(tr: "FlatTrainer"):
+    """(name, offset, numel, shape) of every trainable tensor in flat-buffer order (= Adam group order, run.py:330-336)."""
+    out, o = [], 0
+    params = dict(tr.model.named_parameters())
+    for n in tr.names:
+        p = params[n]
+        out.append((n, o, p.numel(), tuple(p.shape)))
+        o += p.numel()
+    return out
+
+
+def optimizer_state_dict(tr: "FlatTrainer") -> dict:
+    """The FlatTrainer's Adam state as `torch.optim.Adam(build_param_groups(model, args)).state_dict()` would hold it."""
+    segs = _segments(tr)
+    state = {}
+    if tr.step_no > 0:
+        for i, (_, o, k, shape) in enumerate(segs):
+            state[i] = {"step": torch.tensor(float(tr.step_no)),
+                        "exp_avg": tr.m[o:o + k].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": tr.v[o:o + k].view(shape).detach().cpu().clone()}
+    groups, i = [], 0
+    lrs = group_lrs(tr.args)
+    for g in GROUP_ORDER:
+        n_g = sum(1 for n in tr.names if adam_group_of(n) == g)
+        groups.append({"lr": lrs[g], "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                       "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                       "params": list(range(i, i + n_g))})
+        i += n_g
+    return {"state": state, "param_groups": groups}
+
+
+def load_optimizer_state_dict(tr: "FlatTrainer", sd: dict) -> None:
+    segs = _segments(tr)
+    n_params = sum(len(g["params"]) for g in sd["param_groups"])
+    if n_params != len(segs):
+        raise ValueError(f"optimizer state holds {n_params} tensors, the model has {len(segs)} trainable ones")
+    step = 0
+    for i, (n, o, k, shape) in enumerate(segs):
+        st = sd["state"].get(i)
+        if st is None:
+            tr.m[o:o + k].zero_()
+            tr.v[o:o + k].zero_()
+            continue
+        if tuple(st["exp_avg"].shape) != shape:
+            raise ValueError(f"optimizer state of parameter {i} ({n}) has shape {tuple(st['exp_avg'].shape)}, expected {shape}")
+        tr.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+        tr.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+        step = max(step, int(float(st["step"])))
+    tr.step_no = step
+
+
+def save_checkpoint(path: str, model, tr: "FlatTrainer") -> None:
+    """`save_model` of data_utils/utils.py:104-110 (model = the bare module, i.e. the reference's `model.module`)."""
+    torch.save({"model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer": optimizer_state_dict(tr),
+                "rng_state": torch.get_rng_state(),
+                "cuda_rng_state": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}, path)
+
+
+def load_checkpoint(path: str, model, tr: "FlatTrainer" = None, strict: bool = True) -> dict:
+    """run.py:262-277: state dict, optimizer state and RNG streams.  Parameters stay views of the flat buffer
+    (`load_state_dict` copies in place)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model_state_dict"], strict=strict)
+    if tr is not None and ck.get("optimizer") is not None:
+        load_optimizer_state_dict(tr, ck["optimizer"])
+    if ck.get("rng_state") is not None:
+        torch.set_rng_state(ck["rng_state"])
+    if ck.get("cuda_rng_state") is not None and torch.cuda.is_available():
+        torch.cuda.set_rng_state(ck["cuda_rng_state"])
+    return ck

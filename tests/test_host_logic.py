@@ -124,3 +124,41 @@ def test_oracle_invariants_padding_has_zero_influence():
     tt[pad] = torch.randn_like(tt[pad]) * 3
     l1, _ = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, P, layers, **kwargs)
     assert torch.equal(l0, l1)
+
+
+def test_checkpoint_format_matches_torch_adam_and_round_trips(tmp_path):
+    """checkpoints carry the reference's keys (utils.py:104-110) and the optimizer entry is a genuine
+    torch.optim.Adam state dict over run.py's five groups — loadable by a stock Adam — and round-trips."""
+    import helpers
+    from iisan_amd import synth, trainer
+    args = helpers.make_args()
+    model = helpers.build_model(args, 30, synth.make_pop_prob(30), cached=True, device="cpu")     # wired + frozen like run.py
+    tr = trainer.FlatTrainer(model, args)
+    g = torch.Generator().manual_seed(3)
+    tr.m.copy_(torch.rand(tr.m.shape, generator=g))
+    tr.v.copy_(torch.rand(tr.v.shape, generator=g))
+    tr.step_no = 7
+    before = tr.flat.clone()
+    sd = trainer.optimizer_state_dict(tr)
+    ref_opt = torch.optim.Adam(trainer.build_param_groups(model, args))
+    ref_sd = ref_opt.state_dict()
+    assert [len(g_["params"]) for g_ in sd["param_groups"]] == [len(g_["params"]) for g_ in ref_sd["param_groups"]] == [2, 9, 51, 56, 28]
+    assert [g_["lr"] for g_ in sd["param_groups"]] == [g_["lr"] for g_ in ref_sd["param_groups"]]
+    ref_opt.load_state_dict(sd)                                  # a stock optimiser accepts it ...
+    flat_params = [p for g_ in ref_opt.param_groups for p in g_["params"]]
+    for i, p in enumerate(flat_params):                          # ... and lands every moment on the right tensor
+        st = ref_opt.state[p]
+        assert st["exp_avg"].shape == p.shape and float(st["step"]) == 7.0
+    path = str(tmp_path / "epoch-3.pt")
+    trainer.save_checkpoint(path, model, tr)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"model_state_dict", "optimizer", "rng_state", "cuda_rng_state"}
+    m0, v0 = tr.m.clone(), tr.v.clone()
+    tr.m.zero_(); tr.v.zero_(); tr.step_no = 0
+    with torch.no_grad():
+        tr.flat.add_(1.0)
+    trainer.load_checkpoint(path, model, tr)
+    assert torch.equal(tr.flat, before) and torch.equal(tr.m, m0) and torch.equal(tr.v, v0) and tr.step_no == 7
+    for n, p in model.named_parameters():                        # still views of the flat buffer
+        if p.requires_grad:
+            assert p.data.untyped_storage().data_ptr() == tr.flat.untyped_storage().data_ptr(), n
