@@ -19,7 +19,6 @@
 //   * XCD-aware tile order: the 32 workgroups of one XCD walk 32 consecutive tiles (n fastest), sharing A row
 //     panels and the weight matrix in that XCD's L2.
 #include "common.h"
-#include "gemm16_epi.h"
 
 namespace {
 
