@@ -460,3 +460,33 @@ def test_production_size_step_meets_the_north_star_tolerance():
         ref, aux = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, P, layers)
     rel = abs(loss.item() - ref.item()) / abs(ref.item())
     assert rel < 1e-3, f"production-size loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e}"
+
+
+def test_padding_slots_have_exactly_zero_influence_on_the_loss():
+    """SURVEY §4 invariant (3) on the HIP path: whatever the taps of padding slots hold, the loss and every gradient are
+    bit-identical — padded columns get -1e4 (exp underflows to exactly 0 in fp32), padded keys -1e9, and a padded
+    history position's output row is dropped by log_mask."""
+    item_num, bs = 60, 5
+    args = helpers.make_args(drop_rate=0.0)
+    b = synth.scientific_batch(bs=bs, seed=9, item_num=item_num, res=8, words=4, vocab=64, lengths=[2, 11, 5, 3, 7])
+    ids = b.ids.view(-1)
+    pad = (ids == 0)
+    assert pad.any() and (~pad).any()
+    P = weights.make_trainable_params(seed=99, cached=True)
+    out = []
+    for scale in (0.0, 37.0):
+        tc = synth.cached_taps(ids, 12, 768, seed=1)
+        tt = synth.cached_taps(ids, 12, 768, seed=2)
+        g = torch.Generator().manual_seed(5)
+        tc[pad] = torch.randn(int(pad.sum()), 13, 768, generator=g) * scale       # garbage on the padding slots
+        tt[pad] = torch.randn(int(pad.sum()), 13, 768, generator=g) * scale
+        m = helpers.build_model(args, item_num, b.pop_prob, cached=True)
+        helpers.load_trainables(m, P)
+        m.train()
+        loss = m(ids.cuda(), tc.view(bs, 11, 13, 768).cuda(), tt.view(bs, 11, 13, 768).cuda(), b.log_mask.cuda(), None)
+        loss.backward()
+        out.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = out
+    assert torch.equal(l0, l1), (l0.item(), l1.item())
+    for k in g0:
+        assert torch.allclose(g0[k], g1[k], rtol=1e-4, atol=1e-7), (k, (g0[k] - g1[k]).abs().max().item())
