@@ -25,7 +25,7 @@ namespace {
 
 // masked keys carry this RAW score (before the log2(e)/8 scaling): every real score is absorbed by it, like HF's
 // additive fp32-min mask, and MASK_RAW * c2 stays finite
-constexpr float MASK_RAW = -1.0e38f;
+constexpr float MASK_RAW = -0x1p126f;      // a power of two: MASK_RAW * c2 is exact, so the fused scale-and-shift below is exactly 0 on all-masked rows
 
 // One workgroup = one item x HPW consecutive heads, software-pipelined: while head h is being computed out of LDS,
 // the Q/K/V registers for head h+1 are already being filled from HBM (measured on the unpipelined version: the load
@@ -76,26 +76,22 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             const int r = r0 + 32 * p;
             // K and V of a head are read by exactly one workgroup, once: non-temporal (634 -> 619 us; nt on the Q loads or
             // on the context stores made it slower)
-            if (r < S) kreg[p] = __builtin_nontemporal_load((const V8*)(kb_ + r * 64 + c * 8));
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kreg[p][e] = (E)0.f;
+            // pad slots (r >= S) re-read the last real row instead of being zero-filled (a clamp instead of four selects
+            // per fragment): their scores are forced to -inf by the per-key limit below and their P is exactly 0
+            kreg[p] = __builtin_nontemporal_load((const V8*)(kb_ + (r < S ? r : S - 1) * 64 + c * 8));
         }
 #pragma unroll
         for (int p = 0; p < VP; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = (r0 + 32 * p) * 4 + r;
-                if (key < S) vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + key * 64 + c * 8));
-                else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vreg[p][r][e] = (E)0.f;
+                vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + (key < S ? key : S - 1) * 64 + c * 8));
             }
     };
 
     load_head(h0);
     for (int r = tid; r < SP; r += 256)
-        sKB[r] = r >= S ? -2.0f : (key_bias ? key_bias[(int64_t)item * S + r] : 0.0f);
+        sKB[r] = r >= S ? -INFINITY : ((key_bias && key_bias[(int64_t)item * S + r] < 0.f) ? MASK_RAW : INFINITY);   // per-key upper limit of the score
 
     // exp(s/8 - m) = exp2(acc * c2 - m2),  c2 = log2(e) / 8
     const float c2 = 0.18033688011112042f;
@@ -170,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                 if (key_bias != nullptr || t * 16 + 16 > S) {
                     const f4 kb = *(const f4*)(sKB + t * 16 + g * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[t][r] = kb[r] < -1.5f ? -INFINITY : (kb[r] < 0.f ? MASK_RAW : sc[t][r]);
+                    for (int r = 0; r < 4; ++r) asm("v_min_f32 %0, %1, %2" : "=v"(sc[t][r]) : "v"(sc[t][r]), "v"(kb[r]));   // +inf keeps, MASK_RAW replaces (every real score is above it), -inf removes a pad slot:
+                                                                                       // one v_min per score (the nested select compiled to ~16 instructions and a branch each; fminf() adds two canonicalising v_max)
                 }
             }
             float mx = -INFINITY;
@@ -181,12 +178,15 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
+            const float mxs = -(mx * c2);
 #pragma unroll
             for (int t = 0; t < NT16; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a = (sc[t][r] - mx) * c2;      // exact 0 at the maximum (an fma with -mx*c2 is not)
-                    const float p = (dbg & 32) ? a : __builtin_amdgcn_exp2f(a);
+                    const float a = fmaf(sc[t][r], c2, mxs);    // one instruction; mxs = -(mx * c2).  At the maximum the result is the
+                                                                  // rounding residue of mx*c2 (<= 1e-6 in magnitude: exp2 = 1 +- 7e-7), and it
+                                                                  // is exactly 0 on all-masked rows because MASK_RAW is a power of two
+                    const float p = __builtin_amdgcn_exp2f(a);          // (a run-time debug select here cost one v_cndmask per score)
                     sc[t][r] = p;
                     sum += p;
                 }

@@ -10,8 +10,7 @@ qkv = (torch.randn(items, heads, 3, S, 64, device="cuda")).half()
 ctx = torch.empty(items * S, heads * 64, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
 flops = items * heads * 4.0 * S * S * 64
-for name, dbg in (("full", 0), ("no Vt write", 1), ("no K write", 16), ("no QK mfma", 2), ("no exp", 32), ("PV 1/7", 4), ("no store", 8),
-                  ("no QK,exp,PV", 2 + 32 + 4), ("staging only", 2 + 32 + 4 + 8), ("nothing", 1 + 16 + 2 + 32 + 4 + 8)):
+for name, dbg in (("full", 0), ("no Vt write", 1), ("no K write", 16), ("no store", 8), ("no LDS writes, no store", 1 + 16 + 8)):
     lib.iisan_set_attn_debug(dbg)
     for _ in range(2):
         lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
