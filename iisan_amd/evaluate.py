@@ -101,3 +101,38 @@ def hit_ndcg(ranks: torch.Tensor, topk: int = 10) -> Tuple[float, float]:
     hit = (r <= topk).to(torch.float64)
     ndcg = torch.where(r <= topk, 1.0 / torch.log2(r + 1.0), torch.zeros_like(r))
     return float(hit.mean()), float(ndcg.mean())
+
+
+def print_metrics(x, Log_file, v_or_t):
+    """The reference's result line (`metrics.py:35-36`): percentages with five decimals, tab separated."""
+    Log_file.info(v_or_t + "_results   {}".format('\t'.join(["{:0.5f}".format(i * 100) for i in x])))
+
+
+@torch.no_grad()
+def eval_model(model, user_history, eval_seq, item_embeddings_image, item_embeddings_text, test_batch_size, args, item_num,
+               Log_file, v_or_t, local_rank):
+    """Same signature, log lines and return value (Hit@10) as the reference's `eval_model` (`metrics.py:157-246`),
+    for `modality == "intra_inter"`: `item_embeddings_text` is the pair `[text, inter]` that
+    `get_MM_item_embeddings` returns.  `eval_seq` maps user index -> item sequence (last = target), `user_history[u]`
+    the items whose scores are set to -inf.  Works with or without an initialised process group; with one, users are
+    sharded like `SequentialDistributedSampler` and the ranks gathered on every rank."""
+    if "inter" not in args.modality or "intra" not in args.modality:
+        raise NotImplementedError("eval_model: only modality 'intra_inter' is on the hot path")
+    m = model.module if hasattr(model, "module") else model
+    text, inter = item_embeddings_text
+    dev = torch.device("cuda", local_rank) if isinstance(local_rank, int) else torch.device(local_rank)
+    topK = 10
+    Log_file.info(v_or_t + "_methods   {}".format('\t'.join(['Hit{}'.format(topK), 'nDCG{}'.format(topK)])))
+    m.eval()
+    item3 = torch.cat([item_embeddings_image.to(dev), text.to(dev), inter.to(dev)], dim=1).float().contiguous()
+    item_emb = ops.LinearFn.apply(item3, m.com_dense.weight, m.com_dense.bias)          # metrics.py:181
+    users = range(len(eval_seq))
+    seqs = [list(eval_seq[u]) for u in users]
+    hists = [[int(i) for i in user_history[u]] for u in users]
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    ranks = evaluate_ranks(m, item_emb, seqs, hists, max_seq_len=args.max_seq_len, batch=test_batch_size, rank=rank, world=world)
+    mean_eval = list(hit_ndcg(ranks, topK))
+    print_metrics(mean_eval, Log_file, v_or_t)
+    return mean_eval[0]

@@ -274,6 +274,39 @@ def test_batched_eval_pipeline_matches_reference_metrics():
     assert abs(hit - float(z["hit10"])) < 1e-6 and abs(ndcg - float(z["ndcg10"])) < 1e-6
 
 
+def test_eval_model_reference_signature_and_log_lines():
+    """`evaluate.eval_model` called exactly like the reference's (`metrics.py:157`, `run.py:486-492`): same Hit@10, and
+    the two log lines `<v_or_t>_methods` / `<v_or_t>_results` in the reference's format (`metrics.py:35-36,174`)."""
+    from iisan_amd import evaluate
+    z, seqs, tables, P = gio.eval_inputs()
+    args = helpers.make_args()
+    model = helpers.build_model(args, int(z["item_num"]), torch.ones(int(z["item_num"]) + 1), cached=True)
+    helpers.load_trainables(model, {k: v for k, v in P.items() if k.startswith("user_encoder.") or k.startswith("com_dense.")})
+
+    class Log:
+        lines = []
+        def info(self, msg): self.lines.append(msg)
+
+    class Wrapped:                       # what DDP hands to eval_model
+        def __init__(self, m): self.module = m
+        def eval(self): self.module.eval()
+
+    log = Log()
+    keep = [u for u, s in enumerate(seqs) if s[-1] not in s[:-1]]          # (targets inside the history rank differently
+    sub = {i: seqs[u] for i, u in enumerate(keep)}                          #  in the reference: -inf ties in argsort)
+    hist = {i: torch.tensor(seqs[u][:-1]) for i, u in enumerate(keep)}
+    hit = evaluate.eval_model(Wrapped(model), hist, sub, tables[0], [tables[1], tables[2]], 16, args, int(z["item_num"]), log, "validation", 0)
+    ref_ranks = torch.from_numpy(z["ranks"])[keep].double()
+    ref_hit = float((ref_ranks <= 10).double().mean())
+    ref_ndcg = float(torch.where(ref_ranks <= 10, 1.0 / torch.log2(ref_ranks + 1.0), torch.zeros_like(ref_ranks)).mean())
+    assert abs(hit - ref_hit) < 1e-9
+    assert log.lines[0] == "validation_methods   Hit10\tnDCG10"
+    assert log.lines[1] == "validation_results   {:0.5f}\t{:0.5f}".format(ref_hit * 100, ref_ndcg * 100)
+    with pytest.raises(NotImplementedError):
+        evaluate.eval_model(Wrapped(model), hist, sub, tables[0], [tables[1], tables[2]], 16, helpers.make_args(modality="intra"),
+                            int(z["item_num"]), log, "validation", 0)
+
+
 def test_tap_cache_feeds_the_cached_path_identically():
     """Cached == Uncached given the cached taps (SURVEY.md §4 invariant 3): build_tap_cache -> CachedIISANAdaptedMModel
     reproduces the Uncached wrapper's embeddings bit for bit."""
