@@ -12,7 +12,8 @@ W = (torch.randn(N, K, device="cuda") * 0.05).half()
 b = torch.randn(N, device="cuda")
 out = torch.empty(M + 256, N, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
-for dbg, label in [(1, "no-epilogue"), (0, "full")]:
+CASES = [(1, "no-epilogue"), (0, "full")] if len(sys.argv) < 2 else [(int(a), f"debug {a}") for a in sys.argv[1:]]
+for dbg, label in CASES:
     lib.iisan_set_gemm16_variant(3 + ((dbg | 16) << 8))
     for _ in range(2):
         lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
