@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = (r0 + 32 * p) * 4 + r;
-                vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + (key < S ? key : S - 1) * 64 + c * 8));
+                // key groups beyond the padded length are never written to LDS: no load for them (with short sequences
+                // — BERT, S = 30 — most lanes are in that case, and their clamped re-reads cost 10 %; for long sequences the
+                // test itself costs 2 %, so it is compiled in for SP <= 64 only)
+                if (SP > 64 || r0 + 32 * p < SP / 4) vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + (key < S ? key : S - 1) * 64 + c * 8));
             }
     };
 
