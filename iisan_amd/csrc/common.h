@@ -100,84 +100,67 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 6 fma instead of libm's branchy erff.
-// Used only where the result is rounded to a 16-bit operand anyway (FC1 epilogue of the frozen encoders).
+// GELU(erf) for results that are rounded to a 16-bit operand anyway (FC1 epilogue of the frozen encoders), with NO
+// transcendental:   gelu(x) = max(x, 0) - a * R(a)^8,   a = min(|x|, 5.5),   R = degree-5 polynomial,
+// where R(a)^8 approximates 0.5 * erfc(a / sqrt 2) (a minimax fit of the gelu error itself over [0, 5.5], three
+// squarings; beyond 5.5 the term is < 1.4e-8 |x|).  Max |gelu error| 1.7e-6 over [-12, 12] in fp32 arithmetic
+// (tools/gelu_fit.py; an fp16 result near 0.01 already rounds by 3.8e-6).  History: libm erff (branchy); A&S 7.1.26
+// (rcp + exp, ~84 VALU cycles per value); A&S 7.1.28 (1 + a1 z + .. + a6 z^6)^-16 packed (6 fma + 4 mul + rcp, ~45
+// cycles; the FC1 epilogue stayed VALU-issue bound, 23 instructions per pair); this form is 5 fma + 3 mul + min + max +
+// fma = 15 instructions per pair with the bias add and the conversion.
+constexpr float GELU_X0 = 5.5f;
+// min(|x|, X0) and max(x, 0) as ONE instruction each: fminf / fmaxf put a canonicalising `v_max x, x` in front (two of
+// the 12 VALU slots per value)
+__device__ __forceinline__ float gelu_absmin(float x) {
+    float r;
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(GELU_X0));
+    return r;
+}
+__device__ __forceinline__ float gelu_relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+constexpr float GELU_C0 = 9.170038104e-01f, GELU_C1 = -9.149338305e-02f, GELU_C2 = -3.171720356e-02f, GELU_C3 = -1.111552469e-03f,
+                GELU_C4 = 1.940784161e-03f, GELU_C5 = -1.910830324e-04f;
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    const float erf_x = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_x);
+    const float a = gelu_absmin(x);
+    float p = fmaf(a, GELU_C5, GELU_C4);
+    p = fmaf(p, a, GELU_C3);
+    p = fmaf(p, a, GELU_C2);
+    p = fmaf(p, a, GELU_C1);
+    p = fmaf(p, a, GELU_C0);
+    p = p * p; p = p * p; p = p * p;
+    return fmaf(-a, p, gelu_relu(x));
 }
-// Two GELUs at once on the packed-fp32 VALU path (v_pk_fma_f32 / v_pk_mul_f32: 2 results per instruction) with a single
-// transcendental per value: erf by Abramowitz-Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16 (|err| <= 3e-7;
-// measured max |gelu error| 7e-7 over [-12, 12]), and gelu(x) = max(x, 0) - 0.5 |x| (1 - erf(|x|/sqrt2)).
-// The 7.1.26 form above costs ~84 VALU cycles per value (rcp + exp at quarter rate, nothing packed), this one ~45; the
-// FC1 epilogue evaluates 128 of them per lane and tile.
+// The same on 8 pairs at once on the packed-fp32 path (v_pk_fma_f32 / v_pk_mul_f32), written step by step across the
+// pairs so that every Horner / squaring step is 8 INDEPENDENT instructions: with one wave per SIMD doing VALU work the
+// dependent chain of a single evaluation (~8 cycles of latency per step) is otherwise exposed.
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 gelu_erf_fast2(f2 x) {
-    f2 ax;
-    ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
-    const f2 z = ax * 0.70710678118654752440f;
-    f2 p = __builtin_elementwise_fma(z, (f2)0.0000430638f, (f2)0.0002765672f);
-    p = __builtin_elementwise_fma(p, z, (f2)0.0001520143f);
-    p = __builtin_elementwise_fma(p, z, (f2)0.0092705272f);
-    p = __builtin_elementwise_fma(p, z, (f2)0.0422820123f);
-    p = __builtin_elementwise_fma(p, z, (f2)0.0705230784f);
-    p = __builtin_elementwise_fma(p, z, (f2)1.0f);
-    p = p * p; p = p * p; p = p * p; p = p * p;
-    f2 r;
-    r[0] = __builtin_amdgcn_rcpf(p[0]); r[1] = __builtin_amdgcn_rcpf(p[1]);      // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
-    f2 mx;
-    mx[0] = fmaxf(x[0], 0.f); mx[1] = fmaxf(x[1], 0.f);
-    return __builtin_elementwise_fma(ax * -0.5f, r, mx);
-}
-// The same on 8 pairs at once, written step by step across the pairs so that every Horner / squaring step is 8
-// INDEPENDENT instructions: with one wave per SIMD doing VALU work the dependent chain of a single evaluation (6 fma +
-// 4 mul + rcp + fma, ~8 cycles of latency each) is otherwise exposed.
 __device__ __forceinline__ void gelu_erf_fast2x8(f2 (&x)[8]) {
-    f2 ax[8], z[8], p[8];
+    f2 a[8], p[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ax[k][0] = fabsf(x[k][0]); ax[k][1] = fabsf(x[k][1]); z[k] = ax[k] * 0.70710678118654752440f; }
+    for (int k = 0; k < 8; ++k) { a[k][0] = gelu_absmin(x[k][0]); a[k][1] = gelu_absmin(x[k][1]); }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(z[k], (f2)0.0000430638f, (f2)0.0002765672f);
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(a[k], (f2)GELU_C5, (f2)GELU_C4);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0001520143f);
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C3);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0092705272f);
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C2);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0422820123f);
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C1);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)0.0705230784f);
+    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], z[k], (f2)1.0f);
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq)
+    for (int sq = 0; sq < 3; ++sq)
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[k] = p[k] * p[k];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        f2 r, mx;
-        r[0] = __builtin_amdgcn_rcpf(p[k][0]); r[1] = __builtin_amdgcn_rcpf(p[k][1]);
-        mx[0] = fmaxf(x[k][0], 0.f); mx[1] = fmaxf(x[k][1], 0.f);
-        x[k] = __builtin_elementwise_fma(ax[k] * -0.5f, r, mx);
+        f2 mx;
+        mx[0] = gelu_relu(x[k][0]); mx[1] = gelu_relu(x[k][1]);
+        x[k] = __builtin_elementwise_fma(-a[k], p[k], mx);
     }
-}
-// scalar twin of gelu_erf_fast2 (same formula, plain v_fma_f32): kept for A/B timing — packed fp32 VALU next to MFMAs can
-// be slower than two plain instructions (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
-__device__ __forceinline__ float gelu_erf_fast1(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752440f;
-    float p = fmaf(z, 0.0000430638f, 0.0002765672f);
-    p = fmaf(p, z, 0.0001520143f);
-    p = fmaf(p, z, 0.0092705272f);
-    p = fmaf(p, z, 0.0422820123f);
-    p = fmaf(p, z, 0.0705230784f);
-    p = fmaf(p, z, 1.0f);
-    p = p * p; p = p * p; p = p * p; p = p * p;
-    const float r = __builtin_amdgcn_rcpf(p);
-    return fmaf(ax * -0.5f, r, fmaxf(x, 0.f));
 }
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
