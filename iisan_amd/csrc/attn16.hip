@@ -234,15 +234,33 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                     }
                 }
             }
-            if (sq < S && !(dbg & 8)) {
-                E* op = ctx + ((int64_t)item * S + sq) * D + h * 64 + g * 4;
+            // A lane holds 4 consecutive head dims (8 B) of its query per 16-dim tile; lanes 16 apart (g, g+1) hold the
+            // neighbouring 8 B.  `v_permlane16_swap` trades the odd lane's piece of tile 2q for the even lane's piece of
+            // tile 2q+1, so every lane owns 16 contiguous bytes and a store instruction writes 16 rows x 64 contiguous
+            // bytes (two 16-byte stores per block instead of four 8-byte ones).
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            u2 pk[4];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    V4 ov;
+            for (int dt = 0; dt < 4; ++dt) {
+                V4 ov;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = T::from_f32(o[dt][r] * inv);
-                    *(V4*)(op + dt * 16) = ov;
+                for (int r = 0; r < 4; ++r) ov[r] = T::from_f32(o[dt][r] * inv);
+                pk[dt] = __builtin_bit_cast(u2, ov);
+            }
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(pk[2 * q2][w], pk[2 * q2 + 1][w], false, false);
+                    pk[2 * q2][w] = sw[0];
+                    pk[2 * q2 + 1][w] = sw[1];
                 }
+            if (sq < S && !(dbg & 8)) {
+                E* op = ctx + ((int64_t)item * S + sq) * D + h * 64 + g * 4 + ((g & 1) ? 12 : 0);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+                    *(u4*)(op + q2 * 32) = (u4){pk[2 * q2][0], pk[2 * q2][1], pk[2 * q2 + 1][0], pk[2 * q2 + 1][1]};
             }
         }
     }
