@@ -274,6 +274,22 @@ def test_batched_eval_pipeline_matches_reference_metrics():
     assert abs(hit - float(z["hit10"])) < 1e-6 and abs(ndcg - float(z["ndcg10"])) < 1e-6
 
 
+def test_overlapped_towers_give_identical_embeddings():
+    """`mm_encoder.overlap_towers` (text tower on a second HIP stream) is a scheduling choice only."""
+    z, vw, bw, b, P = gio.e2e_small_inputs()
+    args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8)
+    model = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+    helpers.load_trainables(model, P)
+    model.eval()
+    img, txt = b.images.cuda(), b.text.cuda()
+    cv0, (tx0, mm0) = model.mm_encoder(img, txt)
+    model.mm_encoder.overlap_towers = True
+    for _ in range(3):
+        cv1, (tx1, mm1) = model.mm_encoder(img, txt)
+        torch.cuda.synchronize()
+        assert torch.equal(cv0, cv1) and torch.equal(tx0, tx1) and torch.equal(mm0, mm1)
+
+
 def test_eval_model_reference_signature_and_log_lines():
     """`evaluate.eval_model` called exactly like the reference's (`metrics.py:157`, `run.py:486-492`): same Hit@10, and
     the two log lines `<v_or_t>_methods` / `<v_or_t>_results` in the reference's format (`metrics.py:35-36,174`)."""
