@@ -170,6 +170,55 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     }
 
     const bool first_split = blockIdx.y == 0;
+    // Epilogue.  In the MFMA layout a lane owns 4 rows x 1 column of a fragment: stores (and the residual / activation
+    // reads) straight from it are 4-byte accesses, 256 B per wave instruction — the [M,64]·[64,768] products of the side
+    // network (3 x 35 MB out, 35 MB residual in) ran at 1 TB/s, 5x their HBM time (rocprofv3, Cached step).  So the tile
+    // goes through LDS once (As is free after the K loop) and every thread handles float4 runs of a row: 16-byte
+    // accesses, 256 contiguous bytes per row.  Atomic accumulation (split-K weight gradients) keeps the direct path.
+    constexpr bool ACC = (FLAGS & G32_ACCUM) != 0;
+    const bool vec_ok = !ACC && n0 + TN <= p.N && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 &&
+                        (!p.resid || ((p.ldr & 3) == 0 && ((uintptr_t)p.resid & 15) == 0)) &&
+                        (!p.act_src || ((uintptr_t)p.act_src & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0);
+    if (vec_ok) {            // block-uniform
+#pragma unroll
+        for (int mf = 0; mf < FM; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < FN; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[0][mf][nf][r];
+#pragma unroll
+                    for (int q = 1; q < KA; ++q) v += acc[q][mf][nf][r];
+                    As[wm * 16 * FM + mf * 16 + fk * 4 + r][wn * 16 * FN + nf * 16 + fi] = v;
+                }
+        __syncthreads();
+        for (int idx = tid; idx < TM * 16; idx += 256) {
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t m = m0 + row;
+            if (m >= p.M) continue;
+            const int n = n0 + c4;
+            const f2v lo = *(const f2v*)&As[row][c4], hi = *(const f2v*)&As[row][c4 + 2];
+            f4 v = {lo[0], lo[1], hi[0], hi[1]};
+            if (p.bias && first_split) v += *(const f4*)(p.bias + n);
+            const int64_t ci = m * p.ldc + n;
+            if (epi & G32_PREACT) *(f4*)((float*)p.act_src + ci) = v;
+            f4 act = {0.f, 0.f, 0.f, 0.f};
+            if (epi & (G32_MUL_RELU_MASK | G32_MUL_GELU_GRAD)) act = *(const f4*)(p.act_src + ci);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                if (epi & G32_RELU) x = fmaxf(x, 0.f);
+                if (epi & G32_GELU) x = gelu_erf(x);
+                if (epi & G32_MUL_RELU_MASK) x = act[e] > 0.f ? x : 0.f;
+                if (epi & G32_MUL_GELU_GRAD) x *= gelu_erf_grad(act[e]);
+                if (epi & G32_DROPOUT) x *= drop_scale(p.drop.seed, p.drop.site, (uint64_t)(ci + e), p.drop.thr24, p.drop.inv_keep);
+                v[e] = x;
+            }
+            if (p.resid && first_split) v += *(const f4*)(p.resid + m * p.ldr + n);
+            *(f4*)(p.C + ci) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int mf = 0; mf < FM; ++mf)
 #pragma unroll
@@ -192,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 if (epi & G32_MUL_GELU_GRAD) v *= gelu_erf_grad(p.act_src[m * p.ldc + n]);
                 if (epi & G32_DROPOUT) v *= drop_scale(p.drop.seed, p.drop.site, (uint64_t)(m * p.ldc + n), p.drop.thr24, p.drop.inv_keep);
                 if (p.resid && first_split) v += p.resid[m * p.ldr + n];
-                if constexpr ((FLAGS & G32_ACCUM) != 0)
+                if constexpr (ACC)
                     atomicAdd(p.C + m * p.ldc + n, v);
                 else
                     p.C[m * p.ldc + n] = v;

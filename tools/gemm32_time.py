@@ -8,7 +8,7 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 for M in (1408, 11264):
     for name, N, K, ta, tb, acc in [("down  [M,768]x[64,768]^T", 64, 768, 0, 0, 0), ("up    [M,64]x[768,64]^T", 768, 64, 0, 0, 0),
-                                    ("dX    [M,768]x[768,64]", 64, 768, 0, 1, 0), ("dWd   [64,M]x[M,768] (+=)", 768, M, 1, 1, 1)]:
+                                    ("dX    [M,768]x[768,64]", 64, 768, 0, 1, 0), ("dF    [M,64]x[64,768]", 768, 64, 0, 1, 0), ("dWd   [64,M]x[M,768] (+=)", 768, M, 1, 1, 1)]:
         if name.startswith("dWd"):
             Mm, Nn, Kk = 64, 768, M
         else:
