@@ -80,7 +80,11 @@ __device__ __forceinline__ void store_tile(float (*S)[LD], const f4 (&v)[ROWS / 
 // 16x16x4 step: the skinny products of the side network ([M,768] -> 64: one column tile, K = 768) took 40 us with 64-row
 // tiles whatever M was (tools/gemm32_time.py) — 22 workgroups at M = 1408, each a 12-us dependent MFMA chain plus LDS
 // traffic — so tiles shrink until the launch fills the chip.
-template <int FLAGS, int TMV>
+// FAST: every tile of every problem of the launch is full, K-ranges are whole K-tiles and all operand rows are 16-byte
+// aligned (checked on the host): the fetch is then one pointer per operand, advanced per K-tile, and unconditional
+// 16-byte loads — the generic fetch spends ~160 VALU + 80 SALU instructions per K-tile on indices, bounds and alignment
+// (PMC), beside 64 MFMAs.
+template <int FLAGS, int TMV, bool FAST>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
     constexpr int TM = TMV;
     constexpr int WM = TMV >= 32 ? 2 : 1, WN = 4 / WM, FM = TMV / 16 / WM, FN = 4 / WN;
@@ -124,10 +128,24 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     // waited for most of a round trip.
     constexpr int DEPTH = 3;
     f4 ra[DEPTH][TM / 16], rb[DEPTH][4];
+    // FAST: this thread's element of K-tile 0 and the strides between its ROWS/16 loads / between K-tiles
+    constexpr int TPRA = TM / 4, TPRB = TN / 4;
+    const float* pa = TA ? p.A + (kbeg + tid / TPRA) * p.lda + m0 + (tid % TPRA) * 4 : p.A + (m0 + (tid >> 4)) * p.lda + kbeg + (tid & 15) * 4;
+    const float* pb = TB ? p.B + (kbeg + tid / TPRB) * p.ldb + n0 + (tid % TPRB) * 4 : p.B + (int64_t)(n0 + (tid >> 4)) * p.ldb + kbeg + (tid & 15) * 4;
+    const int64_t sia = TA ? (int64_t)(256 / TPRA) * p.lda : (int64_t)16 * p.lda, sib = TB ? (int64_t)(256 / TPRB) * p.ldb : (int64_t)16 * p.ldb;
+    const int64_t ska = TA ? (int64_t)TK * p.lda : TK, skb = TB ? (int64_t)TK * p.ldb : TK;
     auto fetch = [&](int slot, int64_t k) {
         if (k < kend) {
-            load_tile<TM>(ra[slot], p.A, p.lda, TA, m0, p.M, k, kend, tid);
-            load_tile<TN>(rb[slot], p.B, p.ldb, TB, n0, p.N, k, kend, tid);
+            if constexpr (FAST) {
+                const int64_t t = (k - kbeg) / TK;
+#pragma unroll
+                for (int i = 0; i < TM / 16; ++i) ra[slot][i] = *(const f4*)(pa + t * ska + i * sia);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[slot][i] = *(const f4*)(pb + t * skb + i * sib);
+            } else {
+                load_tile<TM>(ra[slot], p.A, p.lda, TA, m0, p.M, k, kend, tid);
+                load_tile<TN>(rb[slot], p.B, p.ldb, TB, n0, p.N, k, kend, tid);
+            }
         }
     };
 #pragma unroll
@@ -273,10 +291,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
 }
 
 template <int FLAGS>
-int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, hipStream_t s) {
-    if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64>), grid, dim3(256), 0, s, b, epi);
-    else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32>), grid, dim3(256), 0, s, b, epi);
-    else hipLaunchKernelGGL((gemm32_kernel<FLAGS, 16>), grid, dim3(256), 0, s, b, epi);
+int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, hipStream_t s) {
+    if (fast) {
+        if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64, true>), grid, dim3(256), 0, s, b, epi);
+        else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32, true>), grid, dim3(256), 0, s, b, epi);
+        else hipLaunchKernelGGL((gemm32_kernel<FLAGS, 16, true>), grid, dim3(256), 0, s, b, epi);
+    } else if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64, false>), grid, dim3(256), 0, s, b, epi);
+    else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32, false>), grid, dim3(256), 0, s, b, epi);
+    else hipLaunchKernelGGL((gemm32_kernel<FLAGS, 16, false>), grid, dim3(256), 0, s, b, epi);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
@@ -316,10 +338,17 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
         if (splitk < 1) splitk = 1;
     }
     dim3 grid((unsigned)max_tiles, (unsigned)splitk, (unsigned)nprob);
+    // FAST fetch: full tiles, whole K-tiles per split, 16-byte aligned operand rows — for every problem of the launch
+    bool fast = true;
+    for (int i = 0; i < nprob && fast; ++i) {
+        const Gemm32Prob& q = probs[i];
+        fast = q.M % TM == 0 && q.N % TN == 0 && q.K % TK == 0 &&
+               (q.lda & 3) == 0 && (q.ldb & 3) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.B & 15) == 0;
+    }
     const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
     const int epi = flags & ~structural;
     switch (structural) {
-#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, s)
+#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, fast, s)
         G32_CASE(0);
         G32_CASE(G32_TA);
         G32_CASE(G32_TB);
