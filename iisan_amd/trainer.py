@@ -76,6 +76,9 @@ def build_param_groups(model, args) -> List[dict]:
     return [{"params": groups[g], "lr": lrs[g]} for g in GROUP_ORDER]
 
 
+FLAT_ALIGN = 16          # floats: 64 bytes
+
+
 class FlatTrainer:
     """One training step of the hot path with flat parameter / gradient storage (see module docstring)."""
 
@@ -85,16 +88,23 @@ class FlatTrainer:
         order = {g: i for i, g in enumerate(GROUP_ORDER)}
         named.sort(key=lambda np_: order[adam_group_of(np_[0])])       # stable: groups contiguous
         self.names = [n for n, _ in named]
-        total = sum(p.numel() for _, p in named)
+        # every tensor starts on a 64-byte boundary of the flat buffers: packed back to back, the 21 one-element gates
+        # left every later weight matrix misaligned and the fp32 GEMM fell back to 4-byte loads for it.  The padding
+        # elements are zero parameters with zero gradients: Adam leaves them at zero, the all-reduce carries them along.
+        self.n_params = sum(p.numel() for _, p in named)
+        self.offsets, total = [], 0
+        for _, p in named:
+            self.offsets.append(total)
+            total += (p.numel() + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
         dev = named[0][1].device
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.seg_end, self.seg_lr, o = [], [], 0
         lrs = group_lrs(args)
         cur = None
-        for n, p in named:
+        for (n, p), o in zip(named, self.offsets):
             g = adam_group_of(n)
             if cur is not None and g != cur:
                 self.seg_end.append(o)
@@ -104,8 +114,7 @@ class FlatTrainer:
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view(p.shape)          # parameters become views of the flat buffer
             p.grad = self.grad[o:o + k].view(p.shape)          # and so do their gradients (autograd accumulates in place)
-            o += k
-        self.seg_end.append(o)
+        self.seg_end.append(total)
         self.seg_lr.append(lrs[cur])
         self.step_no = 0
 
@@ -137,13 +146,8 @@ class FlatTrainer:
 
 def _segments(tr: "FlatTrainer"):
     """(name, offset, numel, shape) of every trainable tensor in flat-buffer order (= Adam group order, run.py:330-336)."""
-    out, o = [], 0
     params = dict(tr.model.named_parameters())
-    for n in tr.names:
-        p = params[n]
-        out.append((n, o, p.numel(), tuple(p.shape)))
-        o += p.numel()
-    return out
+    return [(n, o, params[n].numel(), tuple(params[n].shape)) for n, o in zip(tr.names, tr.offsets)]
 
 
 def optimizer_state_dict(tr: "FlatTrainer") -> dict:

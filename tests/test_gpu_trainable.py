@@ -89,7 +89,7 @@ def test_flat_trainer_adam_step_matches_reference():
     helpers.load_trainables(model, P)
     model.eval()
     tr = trainer.FlatTrainer(model, args)
-    assert tr.flat.numel() == 4113877 and len(tr.seg_end) == 5
+    assert tr.n_params == 4113877 and len(tr.seg_end) == 5
     bs, S = b.log_mask.shape
     before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     loss = tr.step(b.ids.cuda().view(-1), taps_cv.view(bs, S + 1, 13, 768).cuda(), taps_tx.view(bs, S + 1, 13, 768).cuda(),

@@ -64,7 +64,8 @@ def test_flat_trainer_storage_is_contiguous_by_group():
     model = helpers.build_model(args, 100, torch.ones(101), cached=True, device="cpu")
     before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     tr = trainer.FlatTrainer(model, args)
-    assert tr.flat.numel() == 4113877 and tr.seg_end[-1] == 4113877 and len(tr.seg_end) == 5
+    assert tr.n_params == 4113877 and tr.seg_end[-1] == tr.flat.numel() and len(tr.seg_end) == 5
+    assert all(o % 16 == 0 for o in tr.offsets) and tr.flat.numel() - tr.n_params < 16 * len(tr.names)
     assert tr.seg_lr == [5e-5, 1e-4, 2e-4, 1e-4, 1e-4]
     base = tr.flat.data_ptr()
     for n, p in model.named_parameters():
@@ -135,8 +136,11 @@ def test_checkpoint_format_matches_torch_adam_and_round_trips(tmp_path):
     model = helpers.build_model(args, 30, synth.make_pop_prob(30), cached=True, device="cpu")     # wired + frozen like run.py
     tr = trainer.FlatTrainer(model, args)
     g = torch.Generator().manual_seed(3)
-    tr.m.copy_(torch.rand(tr.m.shape, generator=g))
-    tr.v.copy_(torch.rand(tr.v.shape, generator=g))
+    real = torch.zeros(tr.flat.numel(), dtype=torch.bool)        # the alignment padding between tensors holds no state
+    for (_, o, k, _) in trainer._segments(tr):
+        real[o:o + k] = True
+    tr.m.copy_(torch.rand(tr.m.shape, generator=g) * real)
+    tr.v.copy_(torch.rand(tr.v.shape, generator=g) * real)
     tr.step_no = 7
     before = tr.flat.clone()
     sd = trainer.optimizer_state_dict(tr)
@@ -156,7 +160,9 @@ def test_checkpoint_format_matches_torch_adam_and_round_trips(tmp_path):
     m0, v0 = tr.m.clone(), tr.v.clone()
     tr.m.zero_(); tr.v.zero_(); tr.step_no = 0
     with torch.no_grad():
-        tr.flat.add_(1.0)
+        for p in model.parameters():                             # (the alignment padding of the flat buffer stays zero)
+            if p.requires_grad:
+                p.add_(1.0)
     trainer.load_checkpoint(path, model, tr)
     assert torch.equal(tr.flat, before) and torch.equal(tr.m, m0) and torch.equal(tr.v, v0) and tr.step_no == 7
     for n, p in model.named_parameters():                        # still views of the flat buffer
