@@ -123,6 +123,19 @@ def bench_cached(a, args, lib, dev, rank, world):
         dist.destroy_process_group()
 
 
+def pmc_traffic(a, world):
+    """Measured memory-side bytes per gemm16 launch of the DEFAULT configuration, from the committed summary of the two PMC
+    passes (tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run, so any other configuration
+    reports null."""
+    default = (a.bs == 128 and a.dtype == "fp16" and not a.full_blocks and not a.dedup and not a.overlap_towers
+               and not a.cached and a.chunk == 0)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not default or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["avg_bytes_per_launch"])
+
+
 def cpu_baseline(seed=5, budget_s=30.0):
     """The CPU oracle (a port of the reference path, pinned against the reference's golden vectors) timed on this
     host: Uncached IISAN, fp32, fwd+bwd+Adam, on a bounded sample (bs grows 2 -> 16 sequences while the time budget
@@ -246,7 +259,11 @@ def main():
                        "encoder_blocks": "all tokens in every block (as HF)" if a.full_blocks else
                                          "last block: K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / (MFMA_PEAK / 1e12), "traffic": None,
+                         "frac": gemm_tflops / (MFMA_PEAK / 1e12),
+                         # bytes per launch at the L2's memory side (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes of
+                         # this command with this configuration, profiles/pmc_traffic.json; null for any other configuration)
+                         "traffic": pmc_traffic(a, world),
+                         "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1),
                          "kernel": "gemm16 (gemm16_s256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders; flops = executed, by launch)",
                          "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                          "flop_per_launch": fl.value / max(n_launch, 1),

@@ -290,42 +290,47 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::el
     const E* qb_ = qkv + pair * 3 * S * 64;
     const E* kb_ = qb_ + (int64_t)S * 64;
     const E* vb_ = kb_ + (int64_t)S * 64;
-    float q[64];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    // Phase 1: 8 lanes per key (16 bytes of the 128-byte K row each), 8 keys per load instruction — every instruction
+    // reads complete lines.  (The first version gave each lane a whole row: 64 lines touched per instruction, 16 bytes of
+    // each; with 32 waves per CU doing that the lines fell out of L1 and L2 between a lane's 8 loads — PMC: 2.47 GB
+    // fetched per launch for 0.85 GB of K and V.)
+    const int kc = lane & 7, kr = lane >> 3;
+    float q[8];
+    {
         // q_cls: the CLS queries come from their own [items, heads*64] projection (the QKV GEMM wrote K and V only)
-        const V8 t = q_cls ? *(const V8*)(q_cls + (item * heads + h) * 64 + c * 8) : *(const V8*)(qb_ + c * 8);
+        const V8 t = q_cls ? *(const V8*)(q_cls + (item * heads + h) * 64 + kc * 8) : *(const V8*)(qb_ + kc * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[c * 8 + e] = T::to_f32(t[e]);
+        for (int e = 0; e < 8; ++e) q[e] = T::to_f32(t[e]);
     }
-    float sc[4];
     float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int key = lane + 64 * i;
-        float a = -INFINITY;
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int key = k0 + kr;
+        float a = 0.f;
         if (key < S) {
-            a = 0.f;
+            const V8 t = *(const V8*)(kb_ + (int64_t)key * 64 + kc * 8);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const V8 t = *(const V8*)(kb_ + (int64_t)key * 64 + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf(q[c * 8 + e], T::to_f32(t[e]), a);
-            }
-            if (key_bias && key_bias[item * S + key] < 0.f) a = MASK_RAW;
+            for (int e = 0; e < 8; ++e) a = fmaf(q[e], T::to_f32(t[e]), a);
         }
-        sc[i] = a;
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        if (key >= S) a = -INFINITY;
+        else if (key_bias && key_bias[item * S + key] < 0.f) a = MASK_RAW;
+        if (kc == 0 && key < 256) sP[wave][key] = a;
         mx = fmaxf(mx, a);
     }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the raw scores are in sP (each wave uses only its own row)
     const float c2 = 0.18033688011112042f;
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float p = __builtin_amdgcn_exp2f((sc[i] - mx) * c2);      // -inf -> 0 for the structural pad keys
+        const int key = lane + 64 * i;
+        const float a = key < S ? sP[wave][key] : -INFINITY;
+        const float p = __builtin_amdgcn_exp2f((a - mx) * c2);      // -inf -> 0 for the structural pad keys
         sum += p;
-        sP[wave][lane + 64 * i] = T::to_f32(T::from_f32(p));
+        sP[wave][key] = T::to_f32(T::from_f32(p));
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);

@@ -208,7 +208,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // per-launch HIP-event timing of the dominant kernel (timing.cpp); used by bench.py only
 bool iisan_timing_on();
-void iisan_timing_pre(hipStream_t s, double flops);
+void iisan_timing_pre(hipStream_t s, double flops, double bytes);
 void iisan_timing_post(hipStream_t s);
 
 // internal launchers shared between translation units -----------------------------------------------------------
