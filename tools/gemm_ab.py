@@ -7,6 +7,10 @@ import sys, os, time, torch
 sys.path.insert(0, os.getcwd())
 from iisan_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+import ctypes
+_probe = ctypes.CDLL(_lib.LIB_PATH)          # older builds lack newer tooling symbols: bind what exists
+for _t in (_lib.SIGNATURES, _lib.EXTRA_SIGNATURES):
+    for _n in [n for n in _t if not hasattr(_probe, n)]: del _t[_n]
 lib = _lib.load()
 M = 277376
 st = torch.cuda.current_stream().cuda_stream
