@@ -24,8 +24,24 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def test_gemm32_misaligned_operands_take_the_generic_fetch(lib):
+    """Full tiles but operands that start 4 bytes off a 16-byte boundary: the launch must not pick the FAST fetch."""
+    M, N, K = 128, 64, 256
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M * K + 1, generator=g).cuda()
+    B = (torch.randn(N * K + 1, generator=g) * 0.1).cuda()
+    C = torch.empty(M, N, device="cuda")
+    _lib.check(lib.iisan_gemm32(A.data_ptr() + 4, B.data_ptr() + 4, None, C.data_ptr(), M, N, K, 0, 0, 0, 0, _stream()), "gemm32")
+    torch.cuda.synchronize()
+    ref = A[1:].view(M, K).double() @ B[1:].view(N, K).double().t()
+    _close(C, ref, 1e-5, 1e-5, "gemm32 misaligned")
+
+
 @pytest.mark.parametrize("case", [(70, 64, 48, 0, 0), (130, 768, 64, 0, 1), (64, 64, 1408, 1, 1), (33, 192, 64, 0, 0),
-                                  (1000, 257, 100, 1, 0), (5, 3, 7, 0, 1)])
+                                  (1000, 257, 100, 1, 0), (5, 3, 7, 0, 1),
+                                  # full tiles, aligned rows: the pointer-advancing FAST fetch, every operand layout
+                                  (128, 768, 64, 0, 0), (1408, 64, 768, 0, 0), (192, 768, 64, 0, 1), (128, 64, 768, 0, 1),
+                                  (256, 128, 128, 1, 0), (64, 768, 2816, 1, 1)])
 def test_gemm32_vs_torch(lib, case):
     M, N, K, ta, tb = case
     g = torch.Generator().manual_seed(M + N + K)
