@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
     typedef typename T::v8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + N floats of bias
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -202,7 +203,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             const int j = pc & 3;
             const uint64_t gb = ((uint64_t)(pc < 4 ? q.g1hi : q.g2hi) << 32) | (pc < 4 ? q.g1lo : q.g2lo);
             S256_FENCE();
-            glds16((const char*)gb + vj[j], smem + (pc < 4 ? q.l1 : q.l2) + j * 1024);
+            // SGPR base + 32-bit lane offset, written as inline asm: the builtin is selected with a 64-bit VGPR address
+            // (a v_lshl_add_u64 per piece between the MFMAs and two address registers read per lane).  Same-box A/B
+            // over 6 rounds: QKV 915 -> 921, O 940 -> 942, FC1 921 -> 931, FC2 1146 -> 1162 TFLOP/s.  (M0 is only
+            // written here and, in the prologue, by the builtin right before its own use.)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(smem_lds + (pc < 4 ? q.l1 : q.l2) + j * 1024), "v"(vj[j]), "s"(gb) : "memory");
             S256_FENCE();
         };
         auto slice = [&](auto FIRST, int ks) {

@@ -25,7 +25,7 @@ for name, N, K, mode in [("qkv", 2304, 768, 0), ("o", 768, 768, 0), ("fc1", 3072
     out_s.append(f"{name} {2.0 * M * N * K / dt / 1e12:6.0f}")
 print("  ".join(out_s))
 '''
-for rnd in range(3):
+for rnd in range(int(os.environ.get("ROUNDS", "3"))):
     for lib in sys.argv[1:]:
         r = subprocess.run([sys.executable, "-c", CHILD, lib], capture_output=True, text=True)
         print(f"{os.path.basename(lib):24s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
