@@ -505,6 +505,44 @@ def test_versa_at_baseline_config5_widths_matches_oracle():
     assert worst > 0.0
 
 
+def test_inbatch_ce_at_cached_batch_size_matches_the_formula():
+    """BASELINE config C3 (Cached, bs = 1024): logits [10240, 11264].  The fused loss and both gradients against the
+    reference's formula (`model.py:81-104`, as restated in oracle.inbatch_logits) evaluated in fp64 on the device —
+    the oracle itself is CPU-sized; its formula is checked against the reference goldens at small sizes."""
+    from iisan_amd import synth
+    bs, S, E = 1024, 10, 64
+    b = synth.scientific_batch(bs=bs, seed=77, res=2, words=2, dup_items=True)     # ids / log_mask / pop_prob (tiny content)
+    g = torch.Generator().manual_seed(5)
+    ids = b.ids.view(-1).cuda()
+    lm = b.log_mask.float().cuda()
+    pop = b.pop_prob.float().cuda()
+    score = (torch.randn(bs * (S + 1), E, generator=g) * 0.3).cuda().requires_grad_(True)
+    prec = (torch.randn(bs * S, E, generator=g) * 0.3).cuda().requires_grad_(True)
+    loss = ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
+    loss.backward()
+    gs, gp = score.grad.clone(), prec.grad.clone()
+
+    sd, pd = score.detach().double().requires_grad_(True), prec.detach().double().requires_grad_(True)
+    M = bs * (S + 1)
+    z = pd @ sd.t() - torch.log(pop[ids]).double()[None, :]
+    col_pad = torch.cat([lm, torch.ones(bs, 1, device="cuda")], 1).view(-1) == 0
+    z = torch.where(col_pad[None, :], torch.full_like(z, -1e4), z)
+    seq_ids = ids.view(bs, S + 1)
+    same = torch.zeros(bs, M, dtype=torch.bool, device="cuda")
+    for p in range(S + 1):
+        same |= ids[None, :] == seq_ids[:, p:p + 1]
+    label = (torch.arange(bs, device="cuda")[:, None] * (S + 1) + torch.arange(1, S + 1, device="cuda")[None, :]).view(-1)
+    reject = same[:, None, :].expand(bs, S, M).reshape(bs * S, M).clone()
+    reject[torch.arange(bs * S, device="cuda"), label] = False
+    z = torch.where(reject, torch.full_like(z, -1e4), z)
+    keep = lm.reshape(-1) != 0
+    ref = torch.nn.functional.cross_entropy(z[keep], label[keep])
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    _close(gs, sd.grad, 2e-4, 1e-9, "d_score at bs=1024")
+    _close(gp, pd.grad, 2e-4, 1e-9, "d_prec at bs=1024")
+
+
 def test_production_size_step_meets_the_north_star_tolerance():
     """The north-star tolerance at PRODUCTION size: ViT-B/16 + BERT-base (12 layers each, seeded weights), the default
     IISAN side network (7 taps per tower), bs = 2 sequences = 22 item slots, fp16 encoder operands, dead-work pruning
