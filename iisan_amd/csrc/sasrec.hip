@@ -111,99 +111,121 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z
     }
 }
 
-// attention forward: one thread per (b, h, q).  Q/K/V: [B*S, E] (head h = columns h*dh..); P: [B,H,S,S]; C: [B*S,E]
-__global__ void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                    const float* __restrict__ log_mask, float* __restrict__ P, float* __restrict__ C,
-                                    int64_t B, int S, int H, int dh, DropCfg drop) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * H * S) return;
-    const int q = (int)(i % S);
-    const int h = (int)((i / S) % H);
-    const int64_t b = i / ((int64_t)S * H);
+// SASRec attention, one 64-thread workgroup per (sequence b, head h); S <= 32, dh <= 64.  Q/K/V: [B*S, E] (head h =
+// columns h*dh..); P: [B,H,S,S]; C: [B*S,E].  The tiles are staged in LDS with coalesced loads and the three small
+// products are spread over the lanes.  (The first version ran one THREAD per (b, h, q) — every thread a serial chain
+// of S*dh dependent global loads: 83 us for bs = 128 and for bs = 1024 alike, 0.3 ms per step with the backward.)
+// The summation orders are those of the first version (e ascending, k ascending), so results are unchanged.
+constexpr int SA_LD = 65, SA_PL = 33;
+
+__global__ __launch_bounds__(64) void sas_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                          const float* __restrict__ V, const float* __restrict__ log_mask,
+                                                          float* __restrict__ P, float* __restrict__ C, int64_t B, int S, int H,
+                                                          int dh, DropCfg drop) {
+    __shared__ float sQ[32 * SA_LD], sK[32 * SA_LD], sV[32 * SA_LD], sS[32 * SA_PL];
+    const int t = threadIdx.x;
+    const int64_t b = blockIdx.x / H;
+    const int h = (int)(blockIdx.x - b * H);
     const int E = H * dh;
     const float temp = sqrtf((float)dh);
-    const float* qr = Q + (b * S + q) * E + h * dh;
-    float sc[32];
-    float mx = -INFINITY;
-    for (int k = 0; k < S; ++k) {
-        const float* kr = K + (b * S + k) * E + h * dh;
+    for (int idx = t; idx < S * dh; idx += 64) {
+        const int r = idx / dh, e = idx - r * dh;
+        const int64_t g = (b * S + r) * E + h * dh + e;
+        sQ[r * SA_LD + e] = Q[g];
+        sK[r * SA_LD + e] = K[g];
+        sV[r * SA_LD + e] = V[g];
+    }
+    __syncthreads();
+    for (int idx = t; idx < S * S; idx += 64) {
+        const int q = idx / S, k = idx - q * S;
         float d = 0.f;
-        for (int e = 0; e < dh; ++e) d += qr[e] * kr[e];
+        for (int e = 0; e < dh; ++e) d += sQ[q * SA_LD + e] * sK[k * SA_LD + e];
         const float m = (k <= q && log_mask[b * S + k] != 0.f) ? 0.f : -1e9f;
-        sc[k] = d / temp + m;
-        mx = fmaxf(mx, sc[k]);
+        sS[q * SA_PL + k] = d / temp + m;
     }
-    float sum = 0.f;
-    for (int k = 0; k < S; ++k) {
-        sc[k] = expf(sc[k] - mx);
-        sum += sc[k];
+    __syncthreads();
+    if (t < S) {
+        const int q = t;
+        float mx = -INFINITY;
+        for (int k = 0; k < S; ++k) mx = fmaxf(mx, sS[q * SA_PL + k]);
+        float sum = 0.f;
+        for (int k = 0; k < S; ++k) {
+            const float p = expf(sS[q * SA_PL + k] - mx);
+            sS[q * SA_PL + k] = p;
+            sum += p;
+        }
+        float* pr = P + ((b * H + h) * S + q) * S;
+        for (int k = 0; k < S; ++k) {
+            float p = sS[q * SA_PL + k] / sum;
+            pr[k] = p;                 // probabilities BEFORE dropout are kept for backward
+            if (drop.thr24) p *= drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep);
+            sS[q * SA_PL + k] = p;
+        }
     }
-    float* pr = P + ((b * H + h) * S + q) * S;
-    for (int k = 0; k < S; ++k) {
-        sc[k] /= sum;
-        pr[k] = sc[k];                 // probabilities BEFORE dropout are kept for backward
-        if (drop.thr24) sc[k] *= drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep);
-    }
-    float* cr = C + (b * S + q) * E + h * dh;
-    for (int e = 0; e < dh; ++e) {
+    __syncthreads();
+    for (int idx = t; idx < S * dh; idx += 64) {
+        const int q = idx / dh, e = idx - q * dh;
         float acc = 0.f;
-        for (int k = 0; k < S; ++k) acc += sc[k] * V[(b * S + k) * E + h * dh + e];
-        cr[e] = acc;
+        for (int k = 0; k < S; ++k) acc += sS[q * SA_PL + k] * sV[k * SA_LD + e];
+        C[(b * S + q) * E + h * dh + e] = acc;
     }
 }
 
-// attention backward: one block (64 threads) per sequence b; thread (h, q) first builds dS rows into LDS, then
-// thread (h, k) gathers dK, dV over queries.
+// attention backward, same decomposition: dP = (dC V^T) * mask, dS = P (dP - rowdot) / temp, dQ = dS K, dK = dS^T Q,
+// dV = (P * mask)^T dC.
 __global__ __launch_bounds__(64) void sas_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, const float* __restrict__ P,
                                                           const float* __restrict__ dC, float* __restrict__ dQ,
                                                           float* __restrict__ dK, float* __restrict__ dV, int S, int H, int dh,
                                                           DropCfg drop) {
-    __shared__ float dS[64 * 32];     // [(h*S + q)][k], S <= 32, H*S <= 64
-    __shared__ float sM[64 * 32];     // dropout keep factors of this sequence's probabilities
-    const int64_t b = blockIdx.x;
+    __shared__ float sQ[32 * SA_LD], sK[32 * SA_LD], sV[32 * SA_LD], sD[32 * SA_LD];
+    __shared__ float sP[32 * SA_PL], sM[32 * SA_PL], sDP[32 * SA_PL];      // P, dropout keep factors, dP then dS
     const int t = threadIdx.x;
+    const int64_t b = blockIdx.x / H;
+    const int h = (int)(blockIdx.x - b * H);
     const int E = H * dh;
     const float temp = sqrtf((float)dh);
-    const bool act = t < H * S;
-    const int h = act ? t / S : 0, q = act ? t % S : 0;
-    if (act) {
-        const float* pr = P + ((b * H + h) * S + q) * S;
-        const float* dc = dC + (b * S + q) * E + h * dh;
-        float dp[32];
-        float dot = 0.f;
-        for (int k = 0; k < S; ++k) {
-            const float* vr = V + (b * S + k) * E + h * dh;
-            float d = 0.f;
-            for (int e = 0; e < dh; ++e) d += dc[e] * vr[e];
-            const float mk = drop.thr24 ? drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep) : 1.f;
-            sM[t * 32 + k] = mk;
-            d *= mk;                   // dP = dP_drop * mask/(1-p)
-            dp[k] = d;
-            dot += pr[k] * d;
-        }
-        for (int k = 0; k < S; ++k) dS[t * 32 + k] = pr[k] * (dp[k] - dot) / temp;
-        float* dq = dQ + (b * S + q) * E + h * dh;
-        for (int e = 0; e < dh; ++e) {
-            float acc = 0.f;
-            for (int k = 0; k < S; ++k) acc += dS[t * 32 + k] * K[(b * S + k) * E + h * dh + e];
-            dq[e] = acc;
-        }
+    for (int idx = t; idx < S * dh; idx += 64) {
+        const int r = idx / dh, e = idx - r * dh;
+        const int64_t g = (b * S + r) * E + h * dh + e;
+        sQ[r * SA_LD + e] = Q[g];
+        sK[r * SA_LD + e] = K[g];
+        sV[r * SA_LD + e] = V[g];
+        sD[r * SA_LD + e] = dC[g];
+    }
+    for (int idx = t; idx < S * S; idx += 64) {
+        const int q = idx / S, k = idx - q * S;
+        sP[q * SA_PL + k] = P[((b * H + h) * S + q) * S + k];
     }
     __syncthreads();
-    if (act) {
-        const int k = q;               // this thread now owns key/value row k of head h
-        float* dk = dK + (b * S + k) * E + h * dh;
-        float* dv = dV + (b * S + k) * E + h * dh;
-        for (int e = 0; e < dh; ++e) {
-            float ak = 0.f, av = 0.f;
-            for (int qq = 0; qq < S; ++qq) {
-                ak += dS[(h * S + qq) * 32 + k] * Q[(b * S + qq) * E + h * dh + e];
-                av += P[((b * H + h) * S + qq) * S + k] * sM[(h * S + qq) * 32 + k] * dC[(b * S + qq) * E + h * dh + e];
-            }
-            dk[e] = ak;
-            dv[e] = av;
+    for (int idx = t; idx < S * S; idx += 64) {
+        const int q = idx / S, k = idx - q * S;
+        float d = 0.f;
+        for (int e = 0; e < dh; ++e) d += sD[q * SA_LD + e] * sV[k * SA_LD + e];
+        const float mk = drop.thr24 ? drop_scale(drop.seed, drop.site, (uint64_t)(((b * H + h) * S + q) * S + k), drop.thr24, drop.inv_keep) : 1.f;
+        sM[q * SA_PL + k] = mk;
+        sDP[q * SA_PL + k] = d * mk;       // dP = dP_drop * mask/(1-p)
+    }
+    __syncthreads();
+    if (t < S) {
+        const int q = t;
+        float dot = 0.f;
+        for (int k = 0; k < S; ++k) dot += sP[q * SA_PL + k] * sDP[q * SA_PL + k];
+        for (int k = 0; k < S; ++k) sDP[q * SA_PL + k] = sP[q * SA_PL + k] * (sDP[q * SA_PL + k] - dot) / temp;     // dS
+    }
+    __syncthreads();
+    for (int idx = t; idx < S * dh; idx += 64) {
+        const int r = idx / dh, e = idx - r * dh;
+        const int64_t g = (b * S + r) * E + h * dh + e;
+        float aq = 0.f, ak = 0.f, av = 0.f;
+        for (int k = 0; k < S; ++k) aq += sDP[r * SA_PL + k] * sK[k * SA_LD + e];
+        for (int qq = 0; qq < S; ++qq) {
+            ak += sDP[qq * SA_PL + r] * sQ[qq * SA_LD + e];
+            av += sP[qq * SA_PL + r] * sM[qq * SA_PL + r] * sD[qq * SA_LD + e];
         }
+        dQ[g] = aq;
+        dK[g] = ak;
+        dV[g] = av;
     }
 }
 
@@ -245,6 +267,7 @@ int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {
     IISAN_CHECK_SHAPE(cfg->emb % 64 == 0 && cfg->emb <= MAXE, "sasrec: d_model %d must be a multiple of 64 and <= %d", cfg->emb, MAXE);
     IISAN_CHECK_SHAPE(cfg->heads > 0 && cfg->emb % cfg->heads == 0, "sasrec: heads %d does not divide d_model %d", cfg->heads, cfg->emb);
     IISAN_CHECK_SHAPE(cfg->seq >= 1 && cfg->seq <= 32 && cfg->seq * cfg->heads <= 64, "sasrec: seq %d x heads %d unsupported", cfg->seq, cfg->heads);
+    IISAN_CHECK_SHAPE(cfg->emb / cfg->heads <= 64, "sasrec: head width %d > 64 unsupported", cfg->emb / cfg->heads);
     IISAN_CHECK_SHAPE(cfg->blocks >= 1 && cfg->blocks <= 8, "sasrec: %d blocks unsupported", cfg->blocks);
     IISAN_CHECK_SHAPE(cfg->dropout >= 0.f && cfg->dropout < 1.f, "sasrec: dropout %.3f out of range", cfg->dropout);
     return IISAN_OK;
@@ -297,7 +320,7 @@ extern "C" int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, con
         Gemm32Prob pr[3] = {prob(xin, E, W(pb(l, 0)), E, nullptr, k.Q, E, T, E, E), prob(xin, E, W(pb(l, 1)), E, nullptr, k.K, E, T, E, E),
                             prob(xin, E, W(pb(l, 2)), E, nullptr, k.V, E, T, E, E)};
         IISAN_TRY(launch_gemm32(pr, 3, 0, s));
-        hipLaunchKernelGGL(sas_attn_fwd_kernel, dim3((unsigned)ceil_div(B * H * S, 128)), dim3(128), 0, s, k.Q, k.K, k.V,
+        hipLaunchKernelGGL(sas_attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, s, k.Q, k.K, k.V,
                            log_mask, k.P, k.C, B, S, H, dh, make_drop(cfg->seed, 1 + 3 * l, pd));
         IISAN_LAUNCH_OK();
         Gemm32Prob pf = prob(k.C, E, W(pb(l, 3)), E, nullptr, k.Zattn, E, T, E, E, xin);        // x + drop(fc(ctx))
@@ -383,7 +406,7 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
         IISAN_TRY(launch_gemm32(&p, 1, G32_TB, s));                                           // dC = g·Wfc
         p = prob(gA, E, k.C, E, nullptr, G(pb(l, 3)), E, E, E, T);
         IISAN_TRY(launch_gemm32(&p, 1, G32_TA | G32_TB | G32_ACCUM, s));                      // dWfc += g^T·C
-        hipLaunchKernelGGL(sas_attn_bwd_kernel, dim3((unsigned)B), dim3(64), 0, s, k.Q, k.K, k.V, k.P, b.dB, b.dQ, b.dK, b.dV, S, H, dh,
+        hipLaunchKernelGGL(sas_attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, s, k.Q, k.K, k.V, k.P, b.dB, b.dQ, b.dK, b.dV, S, H, dh,
                            make_drop(cfg->seed, 1 + 3 * l, pd));
         IISAN_LAUNCH_OK();
         {
