@@ -45,9 +45,15 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs args) {
     const int64_t total = args.M * d4;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / d4;
-        const int c = (int)(i - m * d4) * 4;
+    // (row, column) advanced incrementally: a 64-bit division per element was most of this kernel's time
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t dm = step / d4;
+    const int dc = (int)(step - dm * d4);
+    int64_t m = i0 / d4;
+    int c4 = (int)(i0 - m * d4);
+    for (int64_t i = i0; i < total; i += step, m += dm, c4 += dc) {
+        if (c4 >= d4) { c4 -= d4; ++m; }
+        const int c = c4 * 4;
         const f4 av = *(const f4*)(t.a + m * t.lda + c);
         f4 pv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
         if (t.prev) pv = *(const f4*)(t.prev + m * t.ldp + c);
@@ -72,9 +78,15 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs args) {
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
     float part = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / d4;
-        const int c = (int)(i - m * d4) * 4;
+    // (row, column) advanced incrementally: a 64-bit division per element was most of this kernel's time
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t dm = step / d4;
+    const int dc = (int)(step - dm * d4);
+    int64_t m = i0 / d4;
+    int c4 = (int)(i0 - m * d4);
+    for (int64_t i = i0; i < total; i += step, m += dm, c4 += dc) {
+        if (c4 >= d4) { c4 -= d4; ++m; }
+        const int c = c4 * 4;
         float* dp = t.F + m * t.D + c;
         const f4 df = *(const f4*)dp;
         if (gated) {
