@@ -90,7 +90,9 @@ __device__ __forceinline__ bool id_in_seq(const int* __restrict__ ids32, int64_t
 enum { CE_FWD = 0, CE_DPREC = 1, CE_DSCORE = 2 };
 
 // X rows: prec (FWD, DPREC) or score (DSCORE).  Y rows: the other matrix.
-template <int MODE>
+// RS1: slots per sequence held in registers by the row-fixed passes (11 = the reference's max_seq_len 10 + 1: five fewer
+// id compares per logit than the generic 16)
+template <int MODE, int RS1 = MAXS1>
 __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ prec, const float* __restrict__ score,
                                                       const float* __restrict__ log_mask, CeBufs b, int64_t bs, int S,
                                                       float d_loss, float* __restrict__ dX) {
@@ -147,13 +149,13 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
     }
 
     // FWD / DPREC: this lane's row belongs to one sequence for the whole pass: its ids live in registers
-    const bool fast = S1 <= MAXS1 && S >= 5 && M < (1ll << 31);
-    int rid[MAXS1];
+    const bool fast = S1 <= RS1 && S >= 5 && M < (1ll << 31);
+    int rid[RS1];
 #pragma unroll
-    for (int p = 0; p < MAXS1; ++p) rid[p] = -1;
+    for (int p = 0; p < RS1; ++p) rid[p] = -1;
     if (MODE != CE_DSCORE && fast) {
 #pragma unroll
-        for (int p = 0; p < MAXS1; ++p)
+        for (int p = 0; p < RS1; ++p)
             if (p < S1) rid[p] = b.ids32[row_seq * S1 + p];
     }
     int* myMeta = sMeta[wave];
@@ -207,10 +209,20 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
         }
         __builtin_amdgcn_wave_barrier();
         if (fast && MODE == CE_DSCORE) {
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                bool h = false;
-                for (int p = 0; p < S1; ++p) h |= myMeta[sidx * S1 + p] == col_id;       // wave-uniform addresses: LDS broadcast
-                hitmask |= h ? (1u << sidx) : 0u;
+            if (RS1 == 11 && S1 == 11) {             // the reference's shape: 44 ids = 11 x ds_read_b128, indices known at compile time
+#pragma unroll
+                for (int i = 0; i < 11; ++i) {
+                    typedef int i4 __attribute__((ext_vector_type(4)));
+                    const i4 v = *(const i4*)(myMeta + 4 * i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hitmask |= v[k] == col_id ? (1u << ((4 * i + k) / 11)) : 0u;
+                }
+            } else {
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    bool h = false;
+                    for (int p = 0; p < S1; ++p) h |= myMeta[sidx * S1 + p] == col_id;       // wave-uniform addresses: LDS broadcast
+                    hitmask |= h ? (1u << sidx) : 0u;
+                }
             }
         }
         // Z^T tile: A = Y rows (i = lane&15), B = X rows
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
             for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
         }
         // lane holds z(x, y = y0 + 4g + r)
-        float dz[4];
+        float dz[4], fv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t y = y0 + 4 * g + r;
@@ -260,22 +272,15 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
             else if (col != label) {
                 if (MODE != CE_DSCORE && fast) {
 #pragma unroll
-                    for (int p = 0; p < MAXS1; ++p) hit |= rid[p] == idc;
+                    for (int p = 0; p < RS1; ++p) hit |= rid[p] == idc;
                 } else if (!fast) {
                     hit = id_in_seq(b.ids32, seq, S1, idc);
                 }
                 if (hit) val = MASKV;
             }
             if (MODE == CE_FWD) {
-                if (yok) {
-                    if (val > run_m) {
-                        run_l = run_l * expf(run_m - val) + 1.f;
-                        run_m = val;
-                    } else {
-                        run_l += expf(val - run_m);
-                    }
-                    if (col == label) zlab = val;
-                }
+                fv[r] = yok ? val : -INFINITY;        // folded into the running (max, sum) after the tile, four at a time
+                if (yok && col == label) zlab = val;
             } else {
                 float lse, scale;
                 if (MODE == CE_DPREC) {
@@ -288,6 +293,19 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
                 }
                 const float p = expf(val - lse);
                 dz[r] = (yok && xok) ? (p - (col == label ? 1.f : 0.f)) * scale : 0.f;
+            }
+        }
+        if (MODE == CE_FWD) {
+            // one rescale per tile instead of a data-dependent branch with an exp on both sides per logit (5 exps per 4
+            // logits instead of 8, no divergence); masked logits are finite (MASKV), structural padding is -inf -> 0
+            const float m4 = fmaxf(fmaxf(fv[0], fv[1]), fmaxf(fv[2], fv[3]));
+            const float mn = fmaxf(run_m, m4);
+            if (mn > -INFINITY) {
+                float add = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) add += expf(fv[r] - mn);
+                run_l = run_l * expf(run_m - mn) + add;
+                run_m = mn;
             }
         }
         if (MODE != CE_FWD) {
@@ -380,7 +398,9 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();
-    hipLaunchKernelGGL(ce_pass_kernel<CE_FWD>, dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S, 0.f,
+    if (S + 1 <= 11) hipLaunchKernelGGL((ce_pass_kernel<CE_FWD, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S, 0.f,
+                       (float*)nullptr);
+    else hipLaunchKernelGGL((ce_pass_kernel<CE_FWD, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S, 0.f,
                        (float*)nullptr);
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, b.rowloss, T, b.nvalid, loss);
@@ -401,10 +421,14 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    hipLaunchKernelGGL(ce_pass_kernel<CE_DPREC>, dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+    if (S + 1 <= 11) hipLaunchKernelGGL((ce_pass_kernel<CE_DPREC, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+                       d_loss, d_prec);
+    else hipLaunchKernelGGL((ce_pass_kernel<CE_DPREC, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
                        d_loss, d_prec);
     IISAN_LAUNCH_OK();
-    hipLaunchKernelGGL(ce_pass_kernel<CE_DSCORE>, dim3((unsigned)ceil_div(M, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+    if (S + 1 == 11) hipLaunchKernelGGL((ce_pass_kernel<CE_DSCORE, 11>), dim3((unsigned)ceil_div(M, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
+                       d_loss, d_score);
+    else hipLaunchKernelGGL((ce_pass_kernel<CE_DSCORE, MAXS1>), dim3((unsigned)ceil_div(M, 16)), dim3(256), 0, s, prec, score, log_mask, b, bs, S,
                        d_loss, d_score);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
