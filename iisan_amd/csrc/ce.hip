@@ -226,13 +226,19 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
             }
         }
         // Z^T tile: A = Y rows (i = lane&15), B = X rows
-        f4 z = {0.f, 0.f, 0.f, 0.f};
+        // two independent accumulator chains (a single one is 16 MFMAs each waiting for the previous result)
+        f4 z = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 4; v += 2) {
             const f4 ya = *(const f4*)(myY + j * YLD + 16 * g + 4 * v);
+            const f4 yb = *(const f4*)(myY + j * YLD + 16 * g + 4 * v + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[e], xb[4 * v + 4 + e], z1, 0, 0, 0);
+            }
         }
+        z += z1;
         // lane holds z(x, y = y0 + 4g + r)
         float dz[4], fv[4];
 #pragma unroll
