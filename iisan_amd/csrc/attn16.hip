@@ -64,12 +64,19 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
         const E* qb_ = qkv + ((int64_t)item * heads + h) * 3 * S * 64;
         const E* kb_ = qb_ + (int64_t)S * 64;
         const E* vb_ = kb_ + (int64_t)S * 64;
+        // The lane-dependent offsets are RECOMPUTED here from a laundered thread id: hoisted out of the head loop they
+        // stayed live across it, were spilled (the kernel sits at 256 VGPRs) and every scratch reload is followed by an
+        // `s_waitcnt vmcnt(0)` — which also waits for the prefetch loads in flight and for all earlier context stores.
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int wave = t2 >> 6, j = t2 & 15, g = (t2 >> 4) & 3, c = t2 & 7, r0 = t2 >> 3;
 #pragma unroll
         for (int i = 0; i < MAXQB; ++i) {
             int sq = (wave + 4 * i) * 16 + j;
             sq = sq < S ? sq : S - 1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) qnext[i][kk] = *(const V8*)(qb_ + sq * 64 + kk * 32 + g * 8);
+            for (int kk = 0; kk < 2; ++kk) qnext[i][kk] = *(const V8*)(qb_ + (unsigned)(sq * 64 + kk * 32 + g * 8));   // 32-bit lane offsets from a uniform base: as
+                                                                                              // 64-bit addresses they were spilled (see the store below)
         }
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             // on the context stores made it slower)
             // pad slots (r >= S) re-read the last real row instead of being zero-filled (a clamp instead of four selects
             // per fragment): their scores are forced to -inf by the per-key limit below and their P is exactly 0
-            kreg[p] = __builtin_nontemporal_load((const V8*)(kb_ + (r < S ? r : S - 1) * 64 + c * 8));
+            kreg[p] = __builtin_nontemporal_load((const V8*)(kb_ + (unsigned)((r < S ? r : S - 1) * 64 + c * 8)));
         }
 #pragma unroll
         for (int p = 0; p < VP; ++p)
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                 // key groups beyond the padded length are never written to LDS: no load for them (with short sequences
                 // — BERT, S = 30 — most lanes are in that case, and their clamped re-reads cost 10 %; for long sequences the
                 // test itself costs 2 %, so it is compiled in for SP <= 64 only)
-                if (SP > 64 || r0 + 32 * p < SP / 4) vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + (key < S ? key : S - 1) * 64 + c * 8));
+                if (SP > 64 || r0 + 32 * p < SP / 4) vreg[p][r] = __builtin_nontemporal_load((const V8*)(vb_ + (unsigned)((key < S ? key : S - 1) * 64 + c * 8)));
             }
     };
 
@@ -256,7 +263,12 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                     pk[2 * q2 + 1][w] = sw[1];
                 }
             if (sq < S && !(dbg & 8)) {
-                E* op = ctx + ((int64_t)item * S + sq) * D + h * 64 + g * 4 + ((g & 1) ? 12 : 0);
+                // 32-bit element offset from a wave-uniform base (the launcher checks the tensor is < 2^31 elements): as 64-bit
+                // per-lane addresses these were spilled, and every scratch reload is an `s_waitcnt vmcnt(0)` — which also waits
+                // for the next head's prefetch loads and for every earlier store
+                int g2 = g;
+                asm volatile("" : "+v"(g2));              // (recomputed per block for the same reason as in load_head)
+                E* op = ctx + (size_t)item * S * D + (unsigned)(sq * D + h * 64 + g2 * 4 + ((g2 & 1) ? 12 : 0));
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2)
@@ -383,6 +395,7 @@ int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void
                        hipStream_t s) {
     IISAN_CHECK_SHAPE(items > 0 && S > 0 && heads > 0, "attention16: empty problem");
     IISAN_CHECK_SHAPE(items * heads < (1ll << 31), "attention16: grid too large");
+    IISAN_CHECK_SHAPE((int64_t)S * heads * 64 < (1ll << 31), "attention16: item of %d x %d elements too large", S, heads * 64);
     return dtype16 == IISAN_BF16 ? launch_t<BF16>(qkv, key_bias, ctx, items, S, heads, s)
                                  : launch_t<F16>(qkv, key_bias, ctx, items, S, heads, s);
 }
