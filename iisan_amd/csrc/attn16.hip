@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
     // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
     constexpr int VT_LD = SP > 128 ? 260 : SP + 8;     // 130 dwords = 2 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (264 gave 2-way conflicts, PMC)
     constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
-    constexpr int KP = SP / 32;                       // K passes: 32 rows per pass
+    constexpr int KP = (SP + 31) / 32;                // K passes: 32 rows per pass (the last may be partial: NT16 odd)
     constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass
     __shared__ __attribute__((aligned(16))) char smem[SP * 128 + 64 * VT_LD * 2 + SP * 4];
     char* sK = smem;
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
         sKB[r] = r >= S ? -INFINITY : ((key_bias && key_bias[(int64_t)item * S + r] < 0.f) ? MASK_RAW : INFINITY);   // per-key upper limit of the score
 
     // exp(s/8 - m) = exp2(acc * c2 - m2),  c2 = log2(e) / 8
+    if (NT16 % 2)              // keys SP .. SP+15 of the last P.V step: never loaded, multiplied by P = 0 — must be finite
+        for (int i = tid; i < 64 * 16; i += 256) sVt[(i >> 4) * VT_LD + SP + (i & 15)] = T::from_f32(0.f);
     const float c2 = 0.18033688011112042f;
 #pragma unroll 1
     for (int hi = 0; hi < hpw; ++hi) {
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
             const int r = r0 + 32 * p;
-            if (!(dbg & 16)) *(V8*)(sK + r * 128 + ((c ^ (r & 7)) << 4)) = kreg[p];
+            if ((SP % 32 == 0 || r < SP) && !(dbg & 16)) *(V8*)(sK + r * 128 + ((c ^ (r & 7)) << 4)) = kreg[p];
         }
         // V^T: a thread owns 4 consecutive keys x 8 head dims -> eight 8-byte LDS writes per pass
 #pragma unroll
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             // the wave time in waits).
             f4 sc[NT16];
             {
-                constexpr int KBATCH = (NT16 % 7 == 0) ? 7 : (NT16 % 4 == 0 ? 4 : NT16);   // tiles whose K fragments are requested together (divides NT16)
+                constexpr int KBATCH = NT16 >= 13 ? 7 : (NT16 % 4 == 0 ? 4 : NT16);        // tiles whose K fragments are requested together (13 = 7 + 6)
 #pragma unroll
                 for (int t0 = 0; t0 < NT16; t0 += KBATCH) {
                     V8 kf[KBATCH][2];
@@ -160,9 +162,10 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                     for (int u = 0; u < KBATCH; ++u)
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
-                            kf[u][kk] = *(const V8*)(sK + ((t0 + u) * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
+                            if (t0 + u < NT16) kf[u][kk] = *(const V8*)(sK + ((t0 + u) * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
 #pragma unroll
                     for (int u = 0; u < KBATCH; ++u) {
+                        if (t0 + u >= NT16) continue;
                         f4 acc = {0.f, 0.f, 0.f, 0.f};
                         acc = T::mfma(kf[u][0], qf[i][0], acc);
                         acc = T::mfma(kf[u][1], qf[i][1], acc);
@@ -223,19 +226,20 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                 };
                 V8 vc[4];
                 vload(0, vc);
+                constexpr int NPV = (NT16 + 1) / 2;            // 32-key steps of P.V; with NT16 odd the last one has a zero half
 #pragma unroll
-                for (int kb = 0; kb < NT16 / 2; ++kb) {
+                for (int kb = 0; kb < NPV; ++kb) {
                     V8 vn[4];
-                    if (kb + 1 < NT16 / 2) vload(kb + 1, vn);          // next step's V^T fragments: in flight during the MFMAs
+                    if (kb + 1 < NPV) vload(kb + 1, vn);          // next step's V^T fragments: in flight during the MFMAs
                     V8 pf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         pf[e] = T::from_f32(sc[2 * kb][e]);
-                        pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
+                        pf[4 + e] = 2 * kb + 1 < NT16 ? T::from_f32(sc[2 * kb + 1][e]) : T::from_f32(0.f);
                     }
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) o[dt] = T::mfma(vc[dt], pf, o[dt]);
-                    if (kb + 1 < NT16 / 2) {
+                    if (kb + 1 < NPV) {
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) vc[dt] = vn[dt];
                     }
@@ -379,6 +383,7 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     if (S <= 32) IISAN_ATTN_CASE(2);
     else if (S <= 64) IISAN_ATTN_CASE(4);
     else if (S <= 128) IISAN_ATTN_CASE(8);
+    else if (S <= 208) IISAN_ATTN_CASE(13);   // ViT: 197 tokens = 13 tiles of 16 keys (a 14th would be pure padding)
     else if (S <= 224) IISAN_ATTN_CASE(14);
     else {
         iisan_set_error("attention16: sequence length %d > 224 not supported", S);
