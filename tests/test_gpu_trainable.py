@@ -41,7 +41,10 @@ def test_gemm32_misaligned_operands_take_the_generic_fetch(lib):
                                   (1000, 257, 100, 1, 0), (5, 3, 7, 0, 1),
                                   # full tiles, aligned rows: the pointer-advancing FAST fetch, every operand layout
                                   (128, 768, 64, 0, 0), (1408, 64, 768, 0, 0), (192, 768, 64, 0, 1), (128, 64, 768, 0, 1),
-                                  (256, 128, 128, 1, 0), (64, 768, 2816, 1, 1)])
+                                  (256, 128, 128, 1, 0), (64, 768, 2816, 1, 1),
+                                  # long K ranges on 64 / 32 / 16-row tiles
+                                  (256, 128, 1024, 1, 0), (192, 128, 640, 0, 1), (96, 64, 576, 0, 0), (2816, 192, 512, 0, 0),
+                                  (1408, 1024, 8192, 0, 0)])
 def test_gemm32_vs_torch(lib, case):
     M, N, K, ta, tb = case
     g = torch.Generator().manual_seed(M + N + K)
