@@ -66,7 +66,7 @@ SIGNATURES = {
     "iisan_sasrec_fwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
     "iisan_sasrec_bwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, C.POINTER(vp), vp, sz, vp]),
     "iisan_inbatch_ce_ws_bytes": (sz, [i64, i32]),
-    "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, sz, vp]),
+    "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, sz, vp]),
     "iisan_inbatch_ce_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, sz, vp]),
     "iisan_score_rank": (i32, [vp, vp, i64, i64, i32, vp, i32, vp, vp, vp]),
     "iisan_adam_step": (i32, [vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(f32), i32, i32, f32, f32, f32, f32, vp]),

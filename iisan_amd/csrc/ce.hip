@@ -41,14 +41,14 @@ void carve(WsCarver& c, CeBufs& b, int64_t bs, int S) {
 }
 
 __global__ void ce_prep_kernel(const int64_t* __restrict__ ids, const float* __restrict__ log_mask,
-                               const float* __restrict__ pop, CeBufs b, int64_t bs, int S) {
+                               const float* __restrict__ pop, int64_t n_pop, CeBufs b, int64_t bs, int S) {
     const int64_t M = bs * (S + 1);
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = c / (S + 1);
         const int p = (int)(c - i * (S + 1));
         const int64_t id = ids[c];
         b.ids32[c] = (int)id;
-        b.debias[c] = logf(pop[id]);
+        b.debias[c] = (id >= 0 && id < n_pop) ? logf(pop[id]) : __builtin_nanf("");     // bad id: loud NaN loss, no wild read
         b.colpad[c] = (p < S && log_mask[i * S + p] == 0.f) ? 1 : 0;
     }
 }
@@ -388,10 +388,11 @@ extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
 }
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
-                                    const float* pop_prob, int64_t bs, int32_t S, int32_t Ein, float* loss, void* ws,
-                                    size_t ws_bytes, void* stream) {
+                                    const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,
+                                    void* ws, size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     IISAN_TRY(check(bs, S, Ein));
+    IISAN_CHECK_SHAPE(n_pop > 0, "inbatch_ce_fwd: empty pop_prob table");
     WsCarver c(ws, ws_bytes);
     CeBufs b;
     carve(c, b, bs, S);
@@ -400,7 +401,7 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    hipLaunchKernelGGL(ce_prep_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, s, ids, log_mask, pop_prob, b, bs, S);
+    hipLaunchKernelGGL(ce_prep_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, s, ids, log_mask, pop_prob, n_pop, b, bs, S);
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();

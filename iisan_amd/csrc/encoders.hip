@@ -23,10 +23,14 @@ struct EncBufs {
     void* D16;      // [Tp, D] 16-bit: output of the O GEMM (a residual DELTA, added to the fp32 stream by LayerNorm kernels)
     void* D16b;     // [Tp, D] 16-bit: output of the FC2 GEMM
     float* KB;      // [Mc, W] key bias (BERT)
+    void* Cls;      // [2, Mcp, D] 16-bit: CLS rows of LN(x) and their Q projection in the CLS-only last block
+    int64_t Mcp;    // items per chunk rounded up to a GEMM row tile
 };
 
-size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int D, int F, int64_t kb_elems) {
+size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems) {
     const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
+    b.Mcp = ceil_div(items, 256) * 256;
+    b.Cls = c.take<uint16_t>((size_t)2 * b.Mcp * D);
     b.X = c.take<float>((size_t)Tp * D);
     b.H = c.take<uint16_t>((size_t)Tp * D);
     b.QKV = c.take<uint16_t>((size_t)Tp * 3 * D);
@@ -95,7 +99,7 @@ extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, in
     const int pd = w->channels * w->patch * w->patch;
     WsCarver c(nullptr, 0);
     EncBufs b;
-    return carve(c, b, Mc * (P + 1), w->hidden, w->mlp > pd ? w->mlp : pd, 0);
+    return carve(c, b, Mc * (P + 1), Mc, w->hidden, w->mlp > pd ? w->mlp : pd, 0);
 }
 
 static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images, int img_u8, int64_t M,
@@ -129,7 +133,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
     WsCarver c(ws, ws_bytes);
     EncBufs b;
-    carve(c, b, Mc * T, D, F > pd ? F : pd, 0);
+    carve(c, b, Mc * T, Mc, D, F > pd ? F : pd, 0);
     if (c.overflow || !ws) {
         iisan_set_error("vit_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
@@ -176,9 +180,9 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 pend_o = b.D16;
                 pend_f = b.D16b;
             } else {
-                // CLS rows only; compact [mc, *] views at the front of big buffers that are free at this point
-                void* Hc = (char*)b.F1;                                           // 16-bit [mc, D]   (F1 is free until FC1)
-                void* Qc = (char*)b.F1 + (size_t)mc * D * 2;                      // 16-bit [mc, D]
+                // CLS rows only: compact [mc, D] 16-bit views in their own scratch
+                void* Hc = b.Cls;
+                void* Qc = (char*)b.Cls + (size_t)b.Mcp * D * 2;
                 IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));            // CLS rows of LN1(x)
                 IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
                 IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s, Qc));
@@ -208,7 +212,7 @@ extern "C" size_t iisan_bert_forward_taps_ws_bytes(const iisan_bert_weights* w, 
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
     WsCarver c(nullptr, 0);
     EncBufs b;
-    return carve(c, b, Mc * words, w->hidden, w->mlp, Mc * words);
+    return carve(c, b, Mc * words, Mc, w->hidden, w->mlp, Mc * words);
 }
 
 extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, int64_t M, int32_t words,
@@ -222,7 +226,7 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
     WsCarver c(ws, ws_bytes);
     EncBufs b;
-    carve(c, b, Mc * T, D, F, Mc * T);
+    carve(c, b, Mc * T, Mc, D, F, Mc * T);
     if (c.overflow || !ws) {
         iisan_set_error("bert_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
@@ -253,8 +257,8 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                 if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
             } else {
                 // post-LN tower: the block input H is the 16-bit image of X, so the CLS rows of H are gathered directly
-                void* Hc = (char*)b.F1;                                           // 16-bit [mc, D]   (F1 is free until FC1)
-                void* Qc = (char*)b.F1 + (size_t)mc * D * 2;
+                void* Hc = b.Cls;
+                void* Qc = (char*)b.Cls + (size_t)b.Mcp * D * 2;
                 IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));
                 IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
                 float* Xc = (float*)b.QKV;

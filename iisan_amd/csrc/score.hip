@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void score_rank_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 64; ++e) p[e] = sp[e];
     const int64_t t = target[u];
+    if (t <= 0 || t >= n_items) {            // not an item: never dereferenced, reported as rank -1
+        if (threadIdx.x == 0) ranks[u] = -1;
+        return;
+    }
     const int32_t* hist = history + u * hist_stride;
     bool t_in_hist = false;
     for (int h = 0; h < hist_stride; ++h) t_in_hist |= (hist[h] == (int32_t)t && hist[h] != 0);

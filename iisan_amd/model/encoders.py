@@ -16,8 +16,10 @@ __all__ = ["MM_Encoder", "Vit_Encoder", "Bert_Encoder", "Text_Encoder", "User_En
 
 
 class FrozenVit(nn.Module):
-    """Minimal stand-in for `ViTForImageClassification`: frozen canonical weights as buffers + the trainable
-    `classifier` head the reference re-creates (`Code_Uncached/run.py:56-61`)."""
+    """Minimal stand-in for `ViTForImageClassification`: the frozen canonical weights (a plain dict, NOT part of
+    `state_dict()`: a checkpoint of a model built on this container holds the trainable tensors only) + the trainable
+    `classifier` head the reference re-creates (`Code_Uncached/run.py:56-61`).  Hand a real HF module to `ModelMM`
+    instead when checkpoints must carry the encoder weights under the reference's keys."""
 
     def __init__(self, w: dict, cfg: weights.VitConfig, embedding_dim: int = 64):
         super().__init__()
@@ -61,6 +63,10 @@ def _bert_canonical(bert_model):
     return weights.bert_from_hf(bert_model.state_dict()), cfg
 
 
+def _drop_packed(module, incompatible_keys):
+    module._packed = None
+
+
 class Vit_Encoder(nn.Module):                      # encoders.py:23-31
     def __init__(self, image_net, dtype16: int = _lib.IISAN_F16):
         super().__init__()
@@ -69,6 +75,8 @@ class Vit_Encoder(nn.Module):                      # encoders.py:23-31
         self.dtype16 = dtype16
         self.chunk_items = 0
         self._packed = None
+        # the kernel-layout copy is built lazily from the module's weights: a later load_state_dict must not leave a stale one
+        self.register_load_state_dict_post_hook(_drop_packed)
 
     def packed(self, device) -> enc.PackedVit:
         if self._packed is None or self._packed.device != torch.device(device):
@@ -123,6 +131,7 @@ class Text_Encoder(nn.Module):                     # encoders.py:68-91
         self.dtype16 = dtype16
         self.chunk_items = 0
         self._packed = None
+        self.register_load_state_dict_post_hook(_drop_packed)
 
     def packed(self, device) -> enc.PackedBert:
         if self._packed is None or self._packed.device != torch.device(device):

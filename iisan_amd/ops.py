@@ -41,9 +41,19 @@ DIRECT_PARAM_GRADS = False
 
 def _grad_targets(params: Sequence[torch.Tensor]):
     """(views to hand to the kernel, what backward returns for the parameters)."""
-    if DIRECT_PARAM_GRADS and all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
-                                  for p in params):
-        return [p.grad for p in params], (None,) * len(params)
+    if DIRECT_PARAM_GRADS:
+        views = []
+        for p in params:
+            if not p.requires_grad:
+                views.append(torch.zeros_like(p))     # frozen tensor or placeholder (e.g. the gates of a non-gated fusion): discarded
+                continue
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                views = None
+                break
+            views.append(g)
+        if views is not None:
+            return views, (None,) * len(params)
     _, views = _flat_grads(params)
     return views, tuple(views)
 
@@ -277,7 +287,7 @@ class InbatchCeFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=score.device)
         ws = torch.empty(lib.iisan_inbatch_ce_ws_bytes(bs, S), dtype=torch.uint8, device=score.device)
         _lib.check(lib.iisan_inbatch_ce_fwd(ids.data_ptr(), score.data_ptr(), prec.data_ptr(), log_mask.data_ptr(),
-                                            pop_prob.data_ptr(), bs, S, E, loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            pop_prob.data_ptr(), pop_prob.numel(), bs, S, E, loss.data_ptr(), ws.data_ptr(), ws.numel(),
                                             _stream()), "iisan_inbatch_ce_fwd")
         ctx.ws = ws
         ctx.save_for_backward(ids, score, prec, log_mask, pop_prob)

@@ -15,9 +15,8 @@ from __future__ import annotations
 from typing import Dict, List, Tuple
 
 import torch
-import torch.distributed as dist
 
-from . import ops
+from . import dp, ops
 from .model import CachedIISANAdaptedMModel, IISANAdaptedMModel, VersaIISANAdaptedMModel
 
 GROUP_ORDER = ("text_encoder", "image_net", "recsys", "adapter_cv", "adapter_text")     # optimizer order, run.py:330-336
@@ -102,6 +101,7 @@ class FlatTrainer:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.seg_end, self.seg_lr, o = [], [], 0
+        self._bound = []
         lrs = group_lrs(args)
         cur = None
         for (n, p), o in zip(named, self.offsets):
@@ -113,16 +113,21 @@ class FlatTrainer:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view(p.shape)          # parameters become views of the flat buffer
-            p.grad = self.grad[o:o + k].view(p.shape)          # and so do their gradients (autograd accumulates in place)
+            g = self.grad[o:o + k].view(p.shape)               # and so do their gradients (autograd accumulates in place)
+            p.grad = g
+            self._bound.append((p, g))
         self.seg_end.append(total)
         self.seg_lr.append(lrs[cur])
         self.step_no = 0
 
     def broadcast_params(self):
         if self.world > 1:
-            dist.broadcast(self.flat, src=0)                    # DDP's initial parameter sync (run.py:287)
+            dp.broadcast_(self.flat, src=0)                     # DDP's initial parameter sync (run.py:287)
 
     def step(self, ids, images, text, log_mask) -> torch.Tensor:
+        for p, g in self._bound:                                # a caller's zero_grad(set_to_none=True) detaches p.grad from
+            if p.grad is not g:                                 # the flat buffer: Adam would then step on zeros — rebind
+                p.grad = g
         self.grad.zero_()                                       # optimizer.zero_grad(), run.py:408
         loss = self.model(ids, images, text, log_mask, None)    # run.py:410
         prev, ops.DIRECT_PARAM_GRADS = ops.DIRECT_PARAM_GRADS, True    # kernels accumulate straight into self.grad
@@ -131,7 +136,7 @@ class FlatTrainer:
         finally:
             ops.DIRECT_PARAM_GRADS = prev
         if self.world > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)    # the ONE data-path collective (DDP grad average)
+            dp.allreduce_sum_(self.grad)                        # the ONE data-path collective (DDP grad average)
         self.step_no += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.seg_end, self.seg_lr, self.step_no,
                       grad_scale=1.0 / self.world)              # run.py:413
@@ -141,7 +146,10 @@ class FlatTrainer:
 # ---------------------------------------------------------------------------------------------------------------
 # Checkpoints in the reference's format (`data_utils/utils.py:104-110`, `run.py:262-277`):
 #   {'model_state_dict', 'optimizer', 'rng_state', 'cuda_rng_state'} with `optimizer` a torch.optim.Adam state dict
-#   over the five run.py groups, so a checkpoint written here resumes under the reference's run.py and vice versa.
+#   over the five run.py groups.  With real HF encoder modules inside the model (as run.py builds it) the state dict
+#   carries the reference's full key set and a checkpoint moves between the two programs in either direction; with the
+#   light FrozenVit/FrozenBert containers it holds the 146 trainable tensors only (the reference would have to load it
+#   with strict=False on top of its pretrained encoders).
 # ---------------------------------------------------------------------------------------------------------------
 
 def _segments(tr: "FlatTrainer"):

@@ -188,11 +188,13 @@ int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, const float* l
 /* ------------------------------------------------------------------------------------------------------------
  * In-batch debiased cross-entropy (ModelMM.forward, Code_Uncached/model/model.py:81-104), fused: the [T,M]
  * logits are never materialised.  ids int64 [bs*(S+1)], score fp32 [bs*(S+1),E], prec fp32 [bs*S,E],
- * log_mask fp32 [bs,S], pop_prob fp32 [item_num+1].  loss: 1 float.  row_lse: [bs*S] scratch kept for bwd.
+ * log_mask fp32 [bs,S], pop_prob fp32 [n_pop = item_num+1].  loss: 1 float.  row_lse: [bs*S] scratch kept for bwd.
+ * The library never syncs, so a bad INPUT VALUE cannot come back as a return code: an id outside [0, n_pop) is
+ * not dereferenced and makes the loss NaN (the reference would raise an IndexError at model.py:63).
  * ---------------------------------------------------------------------------------------------------------- */
 size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S);
 int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
-                         const float* pop_prob, int64_t bs, int32_t S, int32_t E, float* loss,
+                         const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t E, float* loss,
                          void* ws, size_t ws_bytes, void* stream);
 /* d_loss: host scalar multiplier (upstream gradient).  d_score [M,E] and d_prec [T,E] are overwritten. */
 int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
@@ -202,7 +204,8 @@ int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* pr
 /* ------------------------------------------------------------------------------------------------------------
  * Eval scoring (eval_model + metrics_topK, Code_Uncached/data_utils/metrics.py:59-67,198-207): for each user
  * the 1-based rank of `target` among items 1..item_num by score = prec . item_emb, history scored -inf, ties
- * towards the lower item id.  history: int32 [U, hist_stride] padded with 0.  ranks: int32 [U].
+ * towards the lower item id.  history: int32 [U, hist_stride] padded with 0.  ranks: int32 [U]; a target outside
+ * 1..item_num is not dereferenced and yields rank -1, history ids outside that range are ignored.
  * ---------------------------------------------------------------------------------------------------------- */
 int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
                      const int32_t* history, int32_t hist_stride, const int32_t* target, int32_t* ranks,

@@ -56,10 +56,13 @@ E2E_VIT = weights.VitConfig(hidden=768, layers=2, heads=12, mlp=512, image=32, p
 E2E_BERT = weights.BertConfig(hidden=768, layers=2, heads=12, mlp=512, vocab=512, max_pos=64)
 
 
-def e2e_small_inputs():
-    z = load("e2e_small.npz")
+E2E_BS8_LENGTHS = (3, 11, 6, 4, 9, 5, 7, 11)
+
+
+def e2e_small_inputs(name="e2e_small", lengths=(3, 11, 6)):
+    z = load(name + ".npz")
     vw, bw = weights.make_vit_weights(E2E_VIT, seed=11), weights.make_bert_weights(E2E_BERT, seed=12)
-    b = synth.scientific_batch(bs=3, seed=31, lengths=[3, 11, 6], dup_items=True, res=32, words=8, vocab=512,
+    b = synth.scientific_batch(bs=len(lengths), seed=31, lengths=list(lengths), dup_items=True, res=32, words=8, vocab=512,
                                item_num=40)
     assert sha(b.images) == str(z["images_sha"]) and np.array_equal(b.text.numpy(), z["text"])
     assert np.array_equal(b.ids.numpy(), z["ids"])

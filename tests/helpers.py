@@ -1,35 +1,2 @@
-"""Shared builders for the tests: reference-style `args` and product models on seeded weights."""
-from types import SimpleNamespace
-
-import torch
-
-from iisan_amd import weights
-
-
-def make_args(**kw):
-    a = dict(max_seq_len=10, l2_weight=0.1, embedding_dim=64, num_attention_heads=2, drop_rate=0.1,
-             transformer_block=2, modality="intra_inter", CV_model_load="vit-base-mae", bert_model_load="bert_base_uncased",
-             word_embedding_dim=768, num_words_title=30, num_words_abstract=0, num_words_body=0,
-             news_attributes=["title"], remove_first="None", side_adapter_vit_list="1,3,5,7,9,11",
-             side_adapter_bert_list="1,3,5,7,9,11", cv_adapter_down_size=64, bert_adapter_down_size=64,
-             adapter_dropout_rate=0.1, adapter_activation="RELU", fusion_method="gated",
-             lr=2e-4, adapter_cv_lr=1e-4, adapter_bert_lr=1e-4, fine_tune_lr_image=1e-4, fine_tune_lr_text=5e-5)
-    a.update(kw)
-    return SimpleNamespace(**a)
-
-
-def build_model(args, item_num, pop, vit_w=None, vit_cfg=None, bert_w=None, bert_cfg=None, cached=False, device="cuda"):
-    """Product `ModelMM` wired the way run.py:161-224 wires the reference (freeze, wrap, re-enable)."""
-    from iisan_amd import trainer
-    from iisan_amd.model import FrozenBert, FrozenVit, ModelMM
-    vit = FrozenVit(vit_w or {}, vit_cfg or weights.VIT_BASE, args.embedding_dim)
-    bert = FrozenBert(bert_w or {}, bert_cfg or weights.BERT_BASE)
-    model = ModelMM(args, item_num, True, vit, bert, pop)
-    trainer.apply_iisan_freeze_rules(model, args, cached=cached)      # cached: False | True | "versa"
-    return model.to(device)
-
-
-def load_trainables(model, P):
-    missing, unexpected = model.load_state_dict({k: v for k, v in P.items()}, strict=False)
-    assert not unexpected, unexpected
-    assert not [m for m in missing if m in P], missing
+"""Shared builders for the tests (the implementations live in the package: `iisan_amd/factory.py`)."""
+from iisan_amd.factory import build_model, load_trainables, make_args  # noqa: F401

@@ -36,7 +36,7 @@ def _worker(rank, world, port, out):
         return torch.cat([P[n].grad.reshape(-1) for n in names])
 
     mine = flat_grad(100 + rank).clone()
-    reduced = dp.allreduce_mean_(mine.clone())
+    reduced = dp.allreduce_sum_(mine.clone()) / world
     both = torch.stack([flat_grad(100 + r) for r in range(world)]).mean(0)
     ok_grad = torch.allclose(reduced, both, rtol=1e-5, atol=1e-8)
     # eval gather: contiguous shards, padded tail, truncated after the gather

@@ -19,8 +19,22 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
+@pytest.fixture
+def gemm_variant(lib, request):
+    """Force one gemm16 kernel family for a test (0 = auto dispatch, 1 = 128x128 v1, 2 = lock-step 256x256 p256,
+    3 = staggered 256x256 s256; `csrc/gemm16.hip:launch_gemm16`) and restore the auto dispatch afterwards."""
+    lib.iisan_set_gemm16_variant(request.param)
+    yield request.param
+    lib.iisan_set_gemm16_variant(0)
+
+
+@pytest.mark.parametrize("gemm_variant", [0, 1, 2, 3], indirect=True)
 @pytest.mark.parametrize("dt", [_lib.IISAN_F16, _lib.IISAN_BF16])
-def test_full_size_taps_match_reference_golden(dt):
+def test_full_size_taps_match_reference_golden(dt, gemm_variant):
+    """All 13 CLS taps of ViT-B/16 and BERT-base against the taps the REAL reference produced (HF modules,
+    `Code_Uncached/model/encoders.py:29-31,81-91`), once per GEMM kernel family: the auto dispatch sends a 4-item
+    batch to the 128x128 kernel, so variants 2 and 3 are what pins the production 256x256 kernels — incl. the
+    head-major QKV scatter epilogue and the attention kernel fed by it — to the reference."""
     z, vw, bw, b = gio.encoders_full_inputs()
     vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda", dt)
     bert = encoders.PackedBert(bw, weights.BERT_BASE, "cuda", dt)
@@ -44,6 +58,38 @@ def test_full_size_taps_match_reference_golden(dt):
     assert torch.equal(tc_ch, tc)
     tt_ch = bert.forward_taps(b.text.cuda(), layers, chunk_items=3).cpu()
     assert torch.equal(tt_ch, tt)
+
+
+def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
+    """BASELINE config 2 shape: 1,408 item slots (bs=128) through the DEFAULT dispatch — the persistent 256x256 kernels
+    on QKV/O/FC1/FC2 (277,376 ViT token rows, 42,240 BERT rows), the production attention grid — must give, within 16-bit
+    operand rounding, the taps of the same items pushed a few at a time through the 128x128 v1 kernels, which
+    `test_full_size_taps_match_reference_golden[variant 1]` pins to the reference.  Encoder rows are independent
+    (`encoders.py:29-31`: a batch is a stack of items), so any difference is a kernel difference."""
+    from iisan_amd import synth
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    b = synth.scientific_batch(bs=128, seed=12345, device="cuda", images_on_device=True)
+    vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda")
+    bert = encoders.PackedBert(bw, weights.BERT_BASE, "cuda")
+    sel = [0, 2, 4, 6, 8, 10, 12]
+    tc = vit.forward_taps(b.images, sel)
+    tt = bert.forward_taps(b.text, sel)
+    assert torch.isfinite(tc).all() and torch.isfinite(tt).all()
+    try:
+        lib.iisan_set_gemm16_variant(1)
+        rc = vit.forward_taps(b.images, sel, chunk_items=8)
+        rt = bert.forward_taps(b.text, sel, chunk_items=8)
+    finally:
+        lib.iisan_set_gemm16_variant(0)
+    assert torch.equal(tc[:, 0], rc[:, 0]) and torch.equal(tt[:, 0], rt[:, 0])        # tap 0 involves no GEMM kernel choice
+    for k in range(1, len(sel)):
+        # two correct fp16-operand executions differ by accumulation order only: far inside the 1.5e-3 budget vs the reference
+        assert _rel(tc[:, k], rc[:, k]) < 4e-4, f"ViT tap {sel[k]}: {_rel(tc[:, k], rc[:, k]):.3e}"
+        assert _rel(tt[:, k], rt[:, k]) < 4e-4, f"BERT tap {sel[k]}: {_rel(tt[:, k], rt[:, k]):.3e}"
+        # and no single slot is off (a mis-addressed tile would corrupt a few rows, not the norm)
+        per_c = (tc[:, k] - rc[:, k]).norm(dim=1) / rc[:, k].norm(dim=1)
+        per_t = (tt[:, k] - rt[:, k]).norm(dim=1) / rt[:, k].norm(dim=1)
+        assert per_c.max().item() < 2e-3 and per_t.max().item() < 2e-3, (sel[k], per_c.max().item(), per_t.max().item())
 
 
 def test_small_config_taps_match_oracle():

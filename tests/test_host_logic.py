@@ -168,3 +168,90 @@ def test_checkpoint_format_matches_torch_adam_and_round_trips(tmp_path):
     for n, p in model.named_parameters():                        # still views of the flat buffer
         if p.requires_grad:
             assert p.data.untyped_storage().data_ptr() == tr.flat.untyped_storage().data_ptr(), n
+
+
+def test_real_huggingface_modules_are_accepted_at_the_boundary():
+    """The drop-in boundary as `Code_Uncached/run.py:50-100,161` uses it: a `ViTForImageClassification` (classifier
+    re-created as Linear(768, 64), run.py:56-61) and a `BertModel(output_hidden_states=True)` built from the values of the
+    reference's `pretrained_models/*/config.json` go straight into the product `ModelMM`.  The weight extraction the HIP
+    encoders pack from (`model/encoders.py:_vit_canonical/_bert_canonical`) must return exactly the weights that were
+    loaded — for the installed transformers' key layout (5.x: `vit.layers.N.attention.q_proj`) and for the reference's
+    pinned 4.20.1 layout (`vit.encoder.layer.N.attention.attention.query`)."""
+    import pytest
+    tf = pytest.importorskip("transformers")
+    from torch import nn
+    from iisan_amd.model import ModelMM
+    from iisan_amd.model.encoders import _bert_canonical, _vit_canonical
+    vcfg, bcfg = weights.VIT_BASE, weights.BERT_BASE
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    hf_v = tf.ViTConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224,
+                        patch_size=16, num_channels=3, qkv_bias=True, layer_norm_eps=1e-12, hidden_act="gelu",
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hf_b = tf.BertConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                         vocab_size=30522, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                         hidden_act="gelu", output_hidden_states=True)
+    vit = tf.ViTForImageClassification(hf_v)
+    missing, unexpected = vit.load_state_dict(weights.vit_to_hf5(vw, vcfg), strict=False)
+    assert not unexpected and all(k.startswith("classifier") for k in missing), (missing, unexpected)
+    vit.classifier = nn.Linear(vit.classifier.in_features, 64)                       # run.py:59-60
+    bert = tf.BertModel(hf_b)
+    missing, unexpected = bert.load_state_dict(weights.bert_to_hf(bw, bcfg), strict=False)
+    assert not unexpected and all("pooler" in k or "position_ids" in k for k in missing), (missing, unexpected)
+
+    args = helpers.make_args()
+    model = ModelMM(args, 100, True, vit, bert, torch.ones(101))
+    trainer.apply_iisan_freeze_rules(model, args, cached=False)
+    # same trainable set and sizes as with the light containers — and as the reference (SURVEY.md App. A: 199,394,773
+    # parameters of which 4,113,877 trainable; the pooler is there and frozen, run.py:83-100)
+    names = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert names == set(weights.trainable_shapes())
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 4113877
+    assert sum(p.numel() for p in model.parameters()) == 199394773
+    assert "mm_encoder.cv_encoder.image_net.vit.embeddings.cls_token" in model.state_dict()
+    assert "mm_encoder.bert_encoder.text_encoders.title.bert_model.embeddings.word_embeddings.weight" in model.state_dict()
+
+    gv, gcfg = _vit_canonical(model.mm_encoder.cv_encoder.image_net)
+    assert gcfg == vcfg and set(gv) == set(vw) and all(torch.equal(gv[k], vw[k]) for k in vw)
+    gb, gbcfg = _bert_canonical(model.mm_encoder.bert_encoder.text_encoders["title"].bert_model)
+    assert gbcfg == bcfg and set(gb) == set(bw) and all(torch.equal(gb[k], bw[k]) for k in bw)
+
+    class Vit4x(nn.Module):                       # the same module as transformers 4.20.1 names its tensors
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.config = inner, inner.config
+
+        def state_dict(self, *a, **k):
+            ren = (("vit.layers.", "vit.encoder.layer."), ("attention.q_proj", "attention.attention.query"),
+                   ("attention.k_proj", "attention.attention.key"), ("attention.v_proj", "attention.attention.value"),
+                   ("attention.o_proj", "attention.output.dense"), ("mlp.fc1", "intermediate.dense"), ("mlp.fc2", "output.dense"))
+            out = {}
+            for key, v in self.inner.state_dict().items():
+                for a_, b_ in ren:
+                    key = key.replace(a_, b_)
+                out[key] = v
+            return out
+
+    is5 = any(k.startswith("vit.layers.") for k in vit.state_dict())
+    g4, _ = _vit_canonical(Vit4x(vit) if is5 else vit)
+    assert any(".encoder.layer." in k for k in (Vit4x(vit) if is5 else vit).state_dict())
+    assert all(torch.equal(g4[k], vw[k]) for k in vw)
+
+
+def test_bench_starts_its_own_ranks_and_describes_the_host():
+    """`python bench.py --gpus N` outside a rank environment must launch N fresh ranks itself (it used to
+    exit non-zero), with the rendezvous on 127.0.0.1 and its own arguments passed through."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(gio.GOLDEN.rstrip("/")), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse(["--gpus", "8", "--steps", "4", "--warmup", "1"])
+    cmd = bench.launch_command(a, ["--gpus", "8", "--steps", "4", "--warmup", "1"], 29123)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29123"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "4", "--warmup", "1"]
+    assert bench.parse([]).bs == 128 and bench.parse(["--cached", "fp32"]).bs == 1024 and bench.parse(["--cached", "fp16", "--versa"]).bs == 128
+    cores, model = bench.host_cpu()
+    assert 1 <= cores <= (os.cpu_count() or 1) and isinstance(model, str) and model

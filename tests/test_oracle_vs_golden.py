@@ -77,8 +77,9 @@ def test_adam_groups_match_reference_rule():
     assert sizes == dict(recsys=51, adapter_cv=56, adapter_text=28, image_net=9, text_encoder=2)
 
 
-def test_e2e_small_matches_reference():
-    z, vw, bw, b, P = gio.e2e_small_inputs()
+@pytest.mark.parametrize("case", ["e2e_small", "e2e_bs8"])
+def test_e2e_small_matches_reference(case):
+    z, vw, bw, b, P = gio.e2e_small_inputs() if case == "e2e_small" else gio.e2e_small_inputs("e2e_bs8", gio.E2E_BS8_LENGTHS)
     P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     with torch.no_grad():
         taps_cv = O.vit_cls_taps(b.images, vw, gio.E2E_VIT)
