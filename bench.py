@@ -220,23 +220,33 @@ class Uncached:
         return self.tr.step(self.ids, b.images, b.text, b.log_mask)
 
     def kernel_family_check(self):
-        """Forward loss of the bench batch through the product's GEMM dispatch (the persistent 256x256 kernels at this size)
-        vs every encoder GEMM forced onto the 128x128 v1 kernels, which the GPU tests pin to the reference's golden taps:
-        the two must agree within the north-star tolerance.  eval mode (no SASRec dropout), no parameter update."""
-        b, out = self.batch, {}
+        """The bench batch through the product's GEMM dispatch (the persistent 256x256 kernels at this size) vs every encoder
+        GEMM forced onto the 128x128 v1 kernels, which the GPU tests pin to the reference's golden taps: the CLS taps of all
+        1,408 slots must agree within 16-bit accumulation-order noise (4e-4 per layer, far inside the 1.5e-3 tap budget) and
+        the forward loss within the north-star 1e-3.  eval mode (no SASRec dropout), no parameter update."""
+        b, loss, taps = self.batch, {}, {}
+        enc = self.model.mm_encoder
+        need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
         self.model.eval()
         try:
             with torch.no_grad():
                 for v in (0, 1):
                     self.lib.iisan_set_gemm16_variant(v)
-                    out[v] = float(self.model(self.ids, b.images, b.text, b.log_mask, None).item())
+                    loss[v] = float(self.model(self.ids, b.images, b.text, b.log_mask, None).item())
+                    taps[v] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
         finally:
             self.lib.iisan_set_gemm16_variant(0)
             self.model.train()
-        rel = abs(out[0] - out[1]) / abs(out[1])
-        if not rel < 1e-3:
-            raise SystemExit(f"bench.py: production GEMM dispatch loss {out[0]} vs 128x128-kernel loss {out[1]} (rel {rel:.2e})")
-        return {"loss_auto_dispatch": out[0], "loss_v1_kernels": out[1], "rel": rel}
+        rel = abs(loss[0] - loss[1]) / abs(loss[1])
+        tap_rel = 0.0
+        for t0, t1 in zip(taps[0], taps[1]):
+            for k in range(1, len(need)):
+                d = ((t0[:, k] - t1[:, k]).double().norm() / t1[:, k].double().norm()).item()
+                tap_rel = max(tap_rel, d)
+        if not (rel < 1e-3 and tap_rel < 4e-4):
+            raise SystemExit(f"bench.py: production GEMM dispatch vs 128x128 kernels: loss {loss[0]} vs {loss[1]} (rel {rel:.2e}), "
+                             f"worst tap layer rel {tap_rel:.2e}")
+        return {"loss_auto_dispatch": loss[0], "loss_v1_kernels": loss[1], "loss_rel": rel, "worst_tap_layer_rel": tap_rel}
 
     def line(self, steps, warmup, dtype="fp16", full_blocks=False, headline=True):
         a, lib, world = self.a, self.lib, self.world
@@ -311,14 +321,17 @@ def host_cpu():
     return max(1, n), model
 
 
-def cpu_baseline(seed=5, bs=16, warm=3, timed=5, budget_s=75.0):
+def cpu_baseline(seed=5, bs=16, warm=3, timed=5, budget_s=100.0):
     """The CPU oracle (a port of the reference path, pinned against the reference's golden vectors) timed on this host:
     BASELINE config 1 = Uncached IISAN, bs=16 (176 item slots), fp32, fwd+bwd+Adam, on all physical cores; warm-up steps,
     then the MEDIAN of the timed steps (3 + 5; fewer only if the time budget runs out, and said so)."""
     import statistics
     from iisan_amd import synth, weights
     from oracle import iisan_oracle as O
-    cores, cpu_model = host_cpu()
+    phys, cpu_model = host_cpu()
+    # torch-CPU at these sizes stops scaling long before a 2-socket host is full: measured on the pool's 2 x EPYC 9575F
+    # (128 physical cores) 7.3 items/s on 128 threads against 15.4-16.7 on 32 — the baseline uses what is fastest
+    cores = min(phys, 32)
     torch.set_num_threads(cores)
     vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
     P = {k: v.clone().requires_grad_(True) for k, v in weights.make_trainable_params(seed=99).items()}
@@ -355,8 +368,10 @@ def cpu_baseline(seed=5, bs=16, warm=3, timed=5, budget_s=75.0):
             break
     med = statistics.median(times)
     return {"value": bs * 11 / med, "unit": "items/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "physical_cores": phys,
             "sample": f"oracle/iisan_oracle.py, BASELINE config 1: Uncached IISAN bs={bs} ({bs * 11} slots), fp32 torch-CPU on "
-                      f"{cores} threads = physical cores of '{cpu_model}'; {len(warm_t)} warm-up + {len(times)} timed "
+                      f"{cores} threads of '{cpu_model}' ({phys} physical cores visible; more threads run slower); "
+                      f"{len(warm_t)} warm-up + {len(times)} timed "
                       f"fwd+bwd+Adam steps, median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f})"}
 
 

@@ -1,0 +1,206 @@
+// Split-operand GEMM for the big TRAINABLE products (fc_* 768x768 layers of the side network, Versa's dim-align
+// projections and their backward products): fp32 operands are split on the device into two fp16 planes,
+//     x * s = hi + lo,   hi = fp16(x*s),  lo = fp16(x*s - hi),   s = power of two chosen from the tensor's amax,
+// and   A·B^T  ~=  (Ah·Bh^T + Ah·Bl^T + Al·Bh^T) / (sA sB)   runs as ONE 16-bit MFMA GEMM with K' = 3K on operand images
+//     A' = [Ah | Ah | Al]   B' = [Bh | Bl | Bh]     (rows of 3*Kp 16-bit elements)
+// through the encoder GEMM kernel (gemm16.hip, fp32 accumulate).  hi and lo together carry 22 mantissa bits of every
+// element within 2^-16 of the tensor's amax (below that the error floor is 2^-38 of amax), the dropped lo·lo term is
+// 2^-22 relative: the product is within a few fp32 ulps of an fp32 FMA chain, at 1/3 of the 16-bit MFMA rate instead of
+// the f32-input matrix cores' 1/16 (MI355X_MICROARCH.md: 2.5 PF vs 157 TF).  The reference computes these Linear
+// layers in fp32 (Code_Cached/model/model.py:333-347, Code_Cached_Asym/model/model.py:400-416).
+//
+// Everything stays on the stream: amax -> scale -> split are kernels, the scales reach the GEMM epilogue through device
+// memory (never the host), so the library still never synchronises.
+#include "common.h"
+
+namespace {
+
+struct SplitArgs {
+    const float* x;        // source, row-major [rows, cols], leading dimension ld (floats)
+    int64_t rows, cols, ld;
+    _Float16* out;         // [out_rows, 3*kp]
+    int64_t out_rows, kp;  // padded operand rows / padded K (multiple of 64)
+    int32_t pattern;       // 0: [hi|hi|lo] (A operand)   1: [hi|lo|hi] (B operand)
+    int32_t trans;         // 1: the operand is x^T (operand row = source column, K runs over source rows)
+    uint32_t* amax_bits;   // in: bit pattern of max|x| (amax kernel)
+    float* inv_scale;      // out: 1/s
+};
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                   uint32_t* amax_bits) {
+    // cols % 4 == 0 and 16-byte aligned rows are checked on the host
+    const int64_t c4 = cols / 4, total = rows * c4;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4, c = (i - r * c4) * 4;
+        const f4 v = *(const f4*)(x + r * ld + c);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+// s = 2^(13 - floor(log2 amax)): the largest element lands in [2^13, 2^14) (fp16 max 65504); amax == 0 or denormal -> s = 1
+__device__ __forceinline__ float scale_of(uint32_t amax_bits) {
+    const int e = (int)(amax_bits >> 23) & 0xff;
+    if (e == 0 || e == 0xff) return 1.0f;
+    return __uint_as_float((uint32_t)(267 - e) << 23);
+}
+
+__device__ __forceinline__ void split1(float xs, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+
+// operand row = source row: one thread per 8 consecutive K elements
+__global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
+    const float s = scale_of(*a.amax_bits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
+    const int64_t g8 = a.kp / 8, total = a.out_rows * g8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / g8, k = (i - r * g8) * 8;
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }
+        if (r < a.rows && k < a.cols) {
+            const float* p = a.x + r * a.ld + k;
+            if (k + 8 <= a.cols) {
+                const f4 v0 = *(const f4*)p, v1 = *(const f4*)(p + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 h, l;
+                    split1(v0[e] * s, h, l); hi[e] = h; lo[e] = l;
+                    split1(v1[e] * s, h, l); hi[4 + e] = h; lo[4 + e] = l;
+                }
+            } else {
+                for (int e = 0; e < 8 && k + e < a.cols; ++e) {
+                    _Float16 h, l;
+                    split1(p[e] * s, h, l); hi[e] = h; lo[e] = l;
+                }
+            }
+        }
+        _Float16* o = a.out + r * 3 * a.kp + k;
+        *(h8*)o = hi;
+        *(h8*)(o + a.kp) = a.pattern ? lo : hi;
+        *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+    }
+}
+
+// operand row = source COLUMN (x^T): 64 x 64 tiles transposed through LDS; K runs over the source rows
+__global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
+    __shared__ float T[64][65];
+    const float s = scale_of(*a.amax_bits);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;      // source rows  = K index
+    const int64_t c0 = (int64_t)blockIdx.y * 64;      // source cols  = operand rows
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (tid >> 4) + 16 * i, cc = (tid & 15) * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        const int64_t r = r0 + rr, c = c0 + cc;
+        if (r < a.rows && c < a.cols) {
+            const float* p = a.x + r * a.ld + c;
+            if (c + 4 <= a.cols) v = *(const f4*)p;
+            else for (int e = 0; e < 4 && c + e < a.cols; ++e) v[e] = p[e];
+        }
+        T[rr][cc] = v[0]; T[rr][cc + 1] = v[1]; T[rr][cc + 2] = v[2]; T[rr][cc + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int w = tid + 256 * i;          // 512 work items: operand row cc (64) x K group kg (8)
+        const int cc = w >> 3, kg = (w & 7) * 8;
+        const int64_t orow = c0 + cc;
+        if (orow >= a.out_rows) continue;
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h, l;
+            split1(T[kg + e][cc] * s, h, l);
+            hi[e] = h; lo[e] = l;
+        }
+        _Float16* o = a.out + orow * 3 * a.kp + r0 + kg;
+        *(h8*)o = hi;
+        *(h8*)(o + a.kp) = a.pattern ? lo : hi;
+        *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+    }
+}
+
+int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
+                  int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, hipStream_t s) {
+    SplitArgs a{};
+    a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.pattern = pattern; a.trans = trans ? 1 : 0;
+    a.amax_bits = amax_bits; a.inv_scale = inv_scale;
+    a.rows = trans ? K : op_rows;
+    a.cols = trans ? op_rows : K;
+    IISAN_CHECK_SHAPE(a.cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "split: source rows must be 16-byte aligned");
+    int64_t blocks = ceil_div(a.rows * (a.cols / 4), 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, a.rows, a.cols, ld, amax_bits);
+    IISAN_LAUNCH_OK();
+    if (!trans) {
+        int64_t b2 = ceil_div(out_rows * (kp / 8), 256);
+        if (b2 > 8192) b2 = 8192;
+        hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)b2), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(split_cols_kernel, dim3((unsigned)(kp / 64), (unsigned)ceil_div(out_rows, 64)), dim3(256), 0, s, a);
+    }
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+}  // namespace
+
+int launch_gemm16_f32(const Gemm16Args& a, int ksplit, hipStream_t s);      // gemm16.hip
+
+size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
+    const int64_t kp = ceil_div(K, 64) * 64, mp = ceil_div(M, 128) * 128, np = ceil_div(N, 128) * 128;
+    return align_up((size_t)mp * 3 * kp * 2, 256) + align_up((size_t)np * 3 * kp * 2, 256) + 256;
+}
+
+// Worth the four extra small launches (amax + split per operand)?  Only the big products.
+bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
+    if (flags & ~(G32_TA | G32_TB | G32_ACCUM)) return false;            // no activation / dropout epilogues
+    if (p.act_src || p.N % 8 || p.ldc % 4) return false;
+    if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return false;
+    if (p.lda % 4 || p.ldb % 4) return false;
+    if (p.resid && (p.ldr != p.ldc)) return false;
+    return 2.0 * (double)p.M * (double)p.N * (double)p.K >= 6e9;
+}
+
+// C[M,N] (=|+=) op(A)[M,K] · op(B)[K,N] + bias (+ resid), same operand conventions as launch_gemm32
+// (A stored [M,K] or, G32_TA, [K,M]; B stored [N,K] or, G32_TB, [K,N]); G32_ACCUM: C += via fp32 atomics (C pre-zeroed
+// or holding the running sum).  `ws` >= gemm_x3_ws_bytes(M, N, K).
+int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
+    IISAN_CHECK_SHAPE(gemm_x3_applicable(p, flags), "gemm_x3: unsupported problem");
+    IISAN_CHECK_SHAPE(ws && ws_bytes >= gemm_x3_ws_bytes(p.M, p.N, p.K), "gemm_x3: workspace too small");
+    const int64_t kp = ceil_div(p.K, 64) * 64, mp = ceil_div(p.M, 128) * 128, np = ceil_div(p.N, 128) * 128;
+    char* w = (char*)ws;
+    _Float16* A16 = (_Float16*)w;
+    w += align_up((size_t)mp * 3 * kp * 2, 256);
+    _Float16* B16 = (_Float16*)w;
+    w += align_up((size_t)np * 3 * kp * 2, 256);
+    uint32_t* amax = (uint32_t*)w;            // [0] A, [1] B
+    float* inv = (float*)(w + 16);            // [0] A, [1] B
+    IISAN_HIP_OK(hipMemsetAsync(amax, 0, 32, s));
+    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, 0, A16, mp, kp, amax, inv, s));
+    // B operand rows = N: stored [N,K] by default, [K,N] under G32_TB (then the operand is the source transposed)
+    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, 1, B16, np, kp, amax + 1, inv + 1, s));
+    Gemm16Args g{};
+    g.A = A16; g.W = B16; g.bias = p.bias; g.out = p.C; g.resid = p.resid;
+    g.M = p.M; g.N = p.N; g.K = (int32_t)(3 * kp); g.lda = g.ldw = (int32_t)(3 * kp); g.ldo = p.ldc;
+    g.inv_a = inv; g.inv_b = inv + 1; g.atomic = (flags & G32_ACCUM) ? 1 : 0;
+    // split K until the launch has ~2 workgroups per CU (the kernel runs two 128x128 tiles per CU)
+    const int64_t tiles = (mp / 128) * (np / 128);
+    int64_t ks = 1;
+    const int64_t nk = 3 * kp / 64;
+    while (tiles * ks < 384 && ks * 2 <= nk / 8 && ks < 64) ks *= 2;
+    if (ks > 1 && !g.atomic) {
+        // partial sums meet in C through atomics: start from bias (+ resid) written by ... a zeroed C
+        IISAN_HIP_OK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, (size_t)p.M, s));
+        g.atomic = 1;
+    }
+    return launch_gemm16_f32(g, (int)ks, s);
+}
