@@ -76,6 +76,8 @@ SIGNATURES = {
     "iisan_attention_cls16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_set_full_blocks": (None, [i32]),
     "iisan_gemm32": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp]),
+    "iisan_gemm_x3_ws_bytes": (sz, [i64, i32, i64]),
+    "iisan_gemm_x3": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp, sz, vp]),
     "iisan_gather_taps": (i32, [i32, vp, i64, vp, vp, i64, i64, vp]),
     "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
 }
@@ -85,6 +87,7 @@ EXTRA_SIGNATURES = {
     "iisan_timing_enable": (None, [i32]),
     "iisan_set_gemm16_variant": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),
+    "iisan_set_x3": (None, [i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),
 }

@@ -226,8 +226,11 @@ struct Gemm16Args {
     int32_t qkv_S, qkv_heads;   // EPI_QKVH16: tokens per item and heads of the head-major QKV layout
     int32_t qkv_which0;         // EPI_QKVH16: first of q|k|v (0..2) the N = (3 - which0)*64*heads columns hold (1 = K and V only)
     int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
+    // EPI_F32 (split-operand GEMM of the trainable path, split.hip): out fp32 = acc * inv_a[0] * inv_b[0] (+ bias) (+ resid)
+    const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
+    int32_t atomic;     // 1: accumulate into out with fp32 atomics (split-K partial sums, weight-gradient +=)
 };
-enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4 };
+enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5 };
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
 // slice the attention kernel streams is then one contiguous block instead of 128-byte pieces at a 4.6 KB stride.
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
@@ -244,6 +247,12 @@ int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)
 int launch_attention_cls16(int dtype16, const void* qkv, const float* key_bias, void* ctx_cls, int64_t items, int S,
                            int heads, hipStream_t s, const void* q_cls = nullptr);   // q_cls: [items, heads*64] 16-bit CLS queries
+
+// split-operand fp32 GEMM on the 16-bit matrix cores (split.hip); same problem description and TA/TB/ACCUM flags as gemm32
+struct Gemm32Prob;
+size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K);
+bool gemm_x3_applicable(const Gemm32Prob& p, int flags);
+int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
 
 struct Gemm32Prob {
     const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;

@@ -14,7 +14,9 @@
 // All fp32.  Every GEMM / column-sum / fusion step of the (up to) three towers is ONE launch with several problems
 // (per-problem shapes, so Versa's 8192-wide text tower and 1024-wide image tower share launches too).  Fusion kernels
 // are HBM-bound (16-byte lanes, taps read in place from the [M, L, D] tap tensor); GEMMs run on the f32 matrix cores
-// (gemm32.hip).  Saved for backward: F, pre-activation U, activation, state per step, the dim-aligned taps.
+// (gemm32.hip), except the LARGE Linear layers (fc_z 768x768 at Cached batch sizes, Versa's 8192 -> 1024 dim-align;
+// forward, dX and dW), which run as split-operand fp16 MFMA GEMMs (split.hip: ~fp32 accuracy at 1/3 of the 16-bit rate).
+// Saved for backward: F, pre-activation U, activation, state per step, the dim-aligned taps.
 #include "common.h"
 
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
@@ -169,7 +171,33 @@ struct SideBufs {
     float* dY[3];                    // [M, H_z]
     float* dU[3];                    // [M, down]
     float* dDP;                      // [M, d]
+    void* x3; size_t x3_bytes;       // scratch of the split-operand GEMM (operand images + scales), null = not used
 };
+
+// 1 (default): the large Linear layers (fc_z, Versa dim-align; forward, dX and dW) run as split-operand fp16 MFMA GEMMs
+// (split.hip); 0: everything on the f32-input matrix cores (gemm32.hip).  Test / bench knob.
+int g_use_x3 = 1;
+
+size_t x3_need(const Plan& p, int64_t M) {
+    if (!g_use_x3) return 0;
+    size_t need = 0;
+    auto consider = [&](int64_t m, int64_t n, int64_t k) {
+        Gemm32Prob q{};
+        q.M = m; q.N = (int32_t)n; q.K = k; q.lda = q.ldb = q.ldc = q.ldr = 4;
+        if (gemm_x3_applicable(q, 0)) { const size_t b = gemm_x3_ws_bytes(m, n, k); if (b > need) need = b; }
+    };
+    for (int z = 0; z < 3; ++z) {
+        consider(M, p.H[z], p.D[z]);      // Y = O Wf^T
+        consider(M, p.D[z], p.H[z]);      // dO = dY Wf
+        consider(p.H[z], p.D[z], M);      // dWf += dY^T O
+    }
+    if (p.align) {
+        const int dw = p.text_wide ? p.D[1] : p.D[0];
+        consider(M, p.D[2], dw);          // DP = tap Pd^T
+        consider(p.D[2], dw, M);          // dPd += dDP^T tap
+    }
+    return need;
+}
 
 void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
     for (int z = 0; z < 3; ++z)
@@ -187,6 +215,20 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         b.dU[z] = c.take<float>((size_t)M * p.r);
     }
     b.dDP = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
+    b.x3_bytes = x3_need(p, M);
+    b.x3 = b.x3_bytes ? (void*)c.take<char>(b.x3_bytes) : nullptr;
+}
+
+// the problems of one launch group: the large ones as split-operand GEMMs, the rest together on the f32 matrix cores
+int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStream_t s) {
+    Gemm32Prob rest[4];
+    int nr = 0;
+    for (int i = 0; i < n; ++i) {
+        if (b.x3 && gemm_x3_applicable(pr[i], flags)) IISAN_TRY(launch_gemm_x3(pr[i], flags, b.x3, b.x3_bytes, s));
+        else rest[nr++] = pr[i];
+    }
+    if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags, s));
+    return IISAN_OK;
 }
 
 Gemm32Prob prob(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int64_t M, int N,
@@ -269,6 +311,14 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 
 }  // namespace
 
+void gemm_x3_set_min_flops(double f);
+// 0 = off, 1 = default (products of at least 6 GFLOP), 2 = every product whose shape allows it (tests: the small golden
+// fixtures then run through the split-operand path too)
+extern "C" void iisan_set_x3(int32_t mode) {
+    g_use_x3 = mode != 0;
+    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 6e9);
+}
+
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {
     Plan p;
     if (make_plan(cfg, p) != IISAN_OK) return 0;
@@ -299,7 +349,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             const int zw = p.text_wide ? 1 : 0;
             Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
                                  b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
-            IISAN_TRY(launch_gemm32(&pd, 1, 0, s));
+            IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
         }
         FuseArgs fa{};
         fa.M = M;
@@ -325,7 +375,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     }
     Gemm32Prob pr[3];
     for (int z = 0; z < 3; ++z) pr[z] = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
-    IISAN_TRY(launch_gemm32(pr, 3, 0, s));
+    IISAN_TRY(gemm_group(pr, 3, 0, b, s));
     for (int z = 0; z < 3; ++z) pr[z] = prob(b.Y[z], p.H[z], c.W(p.p_head[z]), p.H[z], c.W(p.p_head[z] + 1), item3 + z * p.E, 3 * p.E, M, p.E, p.H[z]);
     IISAN_TRY(launch_gemm32(pr, 3, 0, s));
     return IISAN_OK;
@@ -353,9 +403,9 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
     // fc: Y_z = O_z Wf^T + bf
     for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], c.W(p.p_fc[z]), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], p.H[z]);
-    IISAN_TRY(launch_gemm32(pr, 3, G32_TB, s));                                   // dO = dY · Wf
+    IISAN_TRY(gemm_group(pr, 3, G32_TB, b, s));                                   // dO = dY · Wf
     for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], b.O[p.n[z] - 1][z], p.D[z], nullptr, G(p.p_fc[z]), p.D[z], p.H[z], p.D[z], M);
-    IISAN_TRY(launch_gemm32(pr, 3, G32_TA | G32_TB | G32_ACCUM, s));              // dWf += dY^T · O
+    IISAN_TRY(gemm_group(pr, 3, G32_TA | G32_TB | G32_ACCUM, b, s));              // dWf += dY^T · O
     for (int z = 0; z < 3; ++z) { cs_x[z] = b.dY[z]; cs_o[z] = G(p.p_fc[z] + 1); cs_n[z] = p.H[z]; cs_ld[z] = p.H[z]; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
 
@@ -409,7 +459,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
         if (need_dp) {                        // DP = tap_wide · Pd^T + bd
             const int zw = p.text_wide ? 1 : 0, i = sm.mm_i;
             Gemm32Prob pd = prob(b.dDP, p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
-            IISAN_TRY(launch_gemm32(&pd, 1, G32_TA | G32_TB | G32_ACCUM, s));     // dPd += dDP^T · tap
+            IISAN_TRY(gemm_group(&pd, 1, G32_TA | G32_TB | G32_ACCUM, b, s));     // dPd += dDP^T · tap
             const float* X[1] = {b.dDP};
             float* O[1] = {G(p.dpw(i) + 1)};
             int64_t Ms[1] = {M};

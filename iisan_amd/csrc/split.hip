@@ -161,20 +161,30 @@ size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // Worth the four extra small launches (amax + split per operand)?  Only the big products.
-bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
+static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
     if (flags & ~(G32_TA | G32_TB | G32_ACCUM)) return false;            // no activation / dropout epilogues
     if (p.act_src || p.N % 8 || p.ldc % 4) return false;
     if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return false;
     if (p.lda % 4 || p.ldb % 4) return false;
     if (p.resid && (p.ldr != p.ldc)) return false;
-    return 2.0 * (double)p.M * (double)p.N * (double)p.K >= 6e9;
+    return true;
+}
+// below this many FLOPs the four extra small launches (amax + split per operand) cost more than the matrix rate gains
+static double g_x3_min_flops = 6e9;
+void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f; }
+bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
+    return x3_shape_ok(p, flags) && 2.0 * (double)p.M * (double)p.N * (double)p.K >= g_x3_min_flops;
 }
 
 // C[M,N] (=|+=) op(A)[M,K] · op(B)[K,N] + bias (+ resid), same operand conventions as launch_gemm32
 // (A stored [M,K] or, G32_TA, [K,M]; B stored [N,K] or, G32_TB, [K,N]); G32_ACCUM: C += via fp32 atomics (C pre-zeroed
 // or holding the running sum).  `ws` >= gemm_x3_ws_bytes(M, N, K).
+static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
-    IISAN_CHECK_SHAPE(gemm_x3_applicable(p, flags), "gemm_x3: unsupported problem");
+    return launch_gemm_x3_any(p, flags, ws, ws_bytes, s);
+}
+static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
+    IISAN_CHECK_SHAPE(x3_shape_ok(p, flags), "gemm_x3: unsupported problem (flags 0x%x, N %d)", flags, p.N);
     IISAN_CHECK_SHAPE(ws && ws_bytes >= gemm_x3_ws_bytes(p.M, p.N, p.K), "gemm_x3: workspace too small");
     const int64_t kp = ceil_div(p.K, 64) * 64, mp = ceil_div(p.M, 128) * 128, np = ceil_div(p.N, 128) * 128;
     char* w = (char*)ws;
@@ -197,10 +207,28 @@ int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hi
     int64_t ks = 1;
     const int64_t nk = 3 * kp / 64;
     while (tiles * ks < 384 && ks * 2 <= nk / 8 && ks < 64) ks *= 2;
+    if (p.resid && p.resid == p.C) ks = 1;        // in-place residual: C cannot be zeroed for partial sums
     if (ks > 1 && !g.atomic) {
         // partial sums meet in C through atomics: start from bias (+ resid) written by ... a zeroed C
         IISAN_HIP_OK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, (size_t)p.M, s));
         g.atomic = 1;
     }
     return launch_gemm16_f32(g, (int)ks, s);
+}
+
+extern "C" size_t iisan_gemm_x3_ws_bytes(int64_t M, int32_t N, int64_t K) { return gemm_x3_ws_bytes(M, N, K); }
+
+extern "C" int iisan_gemm_x3(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
+                             int32_t ta, int32_t tb, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+    Gemm32Prob p{};
+    p.A = A; p.B = B; p.bias = bias; p.resid = nullptr; p.act_src = nullptr; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = ta ? (int32_t)M : (int32_t)K;
+    p.ldb = tb ? N : (int32_t)K;
+    p.ldc = N; p.ldr = N;
+    const int flags = (ta ? G32_TA : 0) | (tb ? G32_TB : 0) | (accumulate ? G32_ACCUM : 0);
+    // the exported entry point takes any size (tests); the side network asks gemm_x3_applicable() first
+    IISAN_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "gemm_x3: bad shape");
+    Gemm32Prob q = p;
+    return launch_gemm_x3_any(q, flags, ws, ws_bytes, (hipStream_t)stream);
 }

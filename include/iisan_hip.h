@@ -243,6 +243,14 @@ int iisan_attention_cls16(int32_t dtype16, const void* qkv, const float* key_bia
  * accumulate != 0: C += (atomic, split-K capable) */
 int iisan_gemm32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
                  int32_t ta, int32_t tb, int32_t relu, int32_t accumulate, void* stream);
+/* The same product on the 16-bit matrix cores with split operands (csrc/split.hip): each fp32 operand becomes two fp16
+ * planes (hi + lo, power-of-two scale from the tensor's amax) and  A·B^T ~= Ah·Bh^T + Ah·Bl^T + Al·Bh^T  runs as one
+ * fp16 MFMA GEMM over 3K with fp32 accumulation — a few fp32 ulps from the FMA chain, ~5x the f32 matrix rate.  Used by
+ * the side network for its large Linear layers (fc_* 768x768, Versa dim-align).  No activation epilogue; N % 8 == 0;
+ * operands 16-byte aligned; workspace from iisan_gemm_x3_ws_bytes. */
+size_t iisan_gemm_x3_ws_bytes(int64_t M, int32_t N, int64_t K);
+int iisan_gemm_x3(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int64_t K,
+                  int32_t ta, int32_t tb, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Packed device-resident tap store (replaces the 22 `torch.load` calls per sample of
  * Code_Cached/data_utils/dataset.py:29-34,77-90): table [rows, row_elems] in fp32 / fp16 / bf16 (store_dtype), row i =
  * the selected CLS taps of item i flattened ([n_sel, D]); out[m, :] = fp32(table[ids[m], :]).  ids int64 on device,

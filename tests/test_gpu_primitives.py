@@ -132,3 +132,50 @@ def test_attention16_vs_torch(lib, dt, case):
     ref_cls = ref.view(items, S, D)[:, 0]
     err = (ctx_cls.cpu().double() - ref_cls).abs().max().item()
     assert err <= tol, f"attention_cls dt={dt} {case}: max err {err:.3e} > {tol:.3e}"
+
+
+X3_CASES = [
+    # M, N, K, ta, tb, accumulate, scale_a, scale_b
+    (1000, 768, 768, 0, 0, 0, 1.0, 0.03),          # fc_* forward of the side network
+    (1408, 1024, 8192, 0, 0, 0, 0.25, 0.01),       # Versa dim-align (split-K path)
+    (1408, 768, 768, 0, 1, 0, 1e-5, 0.03),         # dX = dY · W, tiny gradients (dynamic scale)
+    (64, 768, 1408, 1, 1, 1, 1e-4, 1.0),           # dW += dY^T · X (both operands transposed, atomic accumulate)
+    (1024, 8192, 1408, 1, 1, 1, 1e-3, 0.25),       # Versa dPd += dDP^T · tap
+    (130, 72, 100, 0, 0, 0, 1.0, 1.0),             # ragged everything
+    (8, 8, 4, 0, 0, 0, 300.0, 1e-8),               # tiny, extreme magnitudes
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_gemm_x3_matches_fp64(lib, case):
+    """Split-operand GEMM (fp32 operands as hi+lo fp16 planes, three MFMA terms, csrc/split.hip) against the product in
+    fp64: within a few fp32 ulps of the result scale — the same class of error as an fp32 FMA chain — for every operand
+    layout the side network uses (`nn.Linear` forward, dX, dW) and for operand magnitudes far from 1."""
+    M, N, K, ta, tb, acc, sa, sb = case
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = (torch.randn((K, M) if ta else (M, K), generator=g) * sa).cuda()
+    B = (torch.randn((K, N) if tb else (N, K), generator=g) * sb).cuda()
+    bias = None if acc else (torch.randn(N, generator=g) * sa * sb).cuda()
+    C0 = (torch.randn(M, N, generator=g) * sa * sb * K ** 0.5).cuda() if acc else None
+    C = C0.clone() if acc else torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(lib.iisan_gemm_x3_ws_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.iisan_gemm_x3(A.data_ptr(), B.data_ptr(), bias.data_ptr() if bias is not None else None, C.data_ptr(),
+                                 M, N, K, ta, tb, acc, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "gemm_x3")
+    Ad = (A.t() if ta else A).double()
+    Bd = (B if tb else B.t()).double()
+    ref = Ad @ Bd
+    if bias is not None:
+        ref = ref + bias.double()[None]
+    if acc:
+        ref = ref + C0.double()
+    assert torch.isfinite(C).all()
+    scale = ref.abs().max().item()
+    err = (C.double() - ref).abs().max().item() / scale
+    # the fp32 product of the same operands, for scale: the split GEMM must be in the same class
+    f32 = (A.t() if ta else A) @ (B if tb else B.t())
+    if bias is not None:
+        f32 = f32 + bias[None]
+    if acc:
+        f32 = f32 + C0
+    err32 = (f32.double() - ref).abs().max().item() / scale
+    assert err < max(4e-6, 8 * err32), (case, err, err32)

@@ -69,8 +69,19 @@ def test_gemm32_vs_torch(lib, case):
         _close(C, ref, 1e-5, 1e-5, f"gemm32 plain {case}")
 
 
+@pytest.fixture
+def x3_mode(lib, request):
+    """Route of the side network's large Linear layers (`csrc/sidenet.hip:gemm_group`): 1 = product default (split-operand
+    fp16 MFMA GEMM for products of >= 6 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
+    shape allows it — so the small reference goldens pin that path too — 0 = f32 matrix cores only."""
+    lib.iisan_set_x3(request.param)
+    yield request.param
+    lib.iisan_set_x3(1)
+
+
+@pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("variant", ["default", "gelu", "rmfirst"])
-def test_cached_model_loss_and_grads_match_reference(variant):
+def test_cached_model_loss_and_grads_match_reference(variant, x3_mode):
     z, b, taps_cv, taps_tx, P, kw = gio.sidenet_full_inputs(variant)
     args = helpers.make_args(adapter_activation="GELU" if variant == "gelu" else "RELU",
                              remove_first="TRUE" if variant == "rmfirst" else "None")
@@ -294,8 +305,9 @@ def test_sasrec_dropout_matches_oracle_with_the_same_masks():
     _close(y0, O.sasrec(x, lm, P, H, L), 2e-5, 2e-5, "eval forward")
 
 
+@pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("variant", ["text_wide_long", "image_wide_long", "equal_rmfirst"])
-def test_versa_model_matches_reference(variant):
+def test_versa_model_matches_reference(variant, x3_mode):
     """IISAN-Versa (Code_Cached_Asym): asymmetric towers with group layer-drop and dim-align, forward + backward."""
     z, b, taps_cv, taps_tx, args, model, P = gio.versa_inputs(variant, device="cuda")
     helpers.load_trainables(model, P)
@@ -511,7 +523,8 @@ def test_versa_packed_tap_store(variant):
     assert torch.isfinite(l_ref) and torch.isfinite(l_st)
 
 
-def test_versa_at_baseline_config5_widths_matches_oracle():
+@pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
+def test_versa_at_baseline_config5_widths_matches_oracle(x3_mode):
     """BASELINE config 5 shapes: image taps [M, 25, 1024] (ViT-L), text taps [M, 81, 8192] (Llama-3-70B token means),
     tap lists of Code_Cached_Asym/script/run_IISAN.py (6 text / 6 image layers + layer 0), dim-align 8192 -> 1024.
     No golden at this size (58 MB of taps per modality for 22 slots): HIP forward/backward against the CPU oracle, which
@@ -722,3 +735,50 @@ def test_out_of_range_ids_are_loud_not_wild_reads():
     hist = torch.zeros(3, 4, dtype=torch.int32).cuda()
     ranks = ops.score_rank(prec[:3].contiguous(), item_emb, hist, torch.tensor([5, n + 7, 0], dtype=torch.int32).cuda()).cpu()
     assert ranks[0] >= 1 and ranks[1] == -1 and ranks[2] == -1
+
+
+@pytest.mark.parametrize("versa", [False, True])
+def test_split_operand_layers_at_bench_size_equal_the_f32_matrix_core_path(lib, versa):
+    """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128) the product routes the
+    large Linear layers through the split-operand GEMM.  Same step with that route switched off (every product on the
+    exact-fp32 matrix cores): loss within 2e-5, every gradient within 5e-4 of its scale — the tolerances the small
+    fixtures hold against the reference."""
+    from iisan_amd import tapstore
+    n = 2000
+    bs = 128 if versa else 1024
+    b = synth.scientific_batch(bs=bs, seed=41, item_num=n, res=2, words=2)
+    ids, lm = b.ids.view(-1).cuda(), b.log_mask.cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    out = {}
+    for mode in (0, 1):
+        lib.iisan_set_x3(mode)
+        try:
+            if versa:
+                args = helpers.make_args(text_embedding_dim=8192, image_embedding_dim=1024, side_adapter_vit_list="3,7,11,15,19,23",
+                                         side_adapter_bert_list="4,19,34,49,64,79", image_layers=24, text_layers=80, drop_rate=0.0)
+                model = helpers.build_model(args, n, b.pop_prob, cached="versa")
+                dims = (1024, 8192)
+            else:
+                args = helpers.make_args(drop_rate=0.0)
+                model = helpers.build_model(args, n, b.pop_prob, cached=True)
+                dims = (768, 768)
+            shapes = {k: tuple(p.shape) for k, p in model.named_parameters() if p.requires_grad}
+            helpers.load_trainables(model, weights.fill_params_seeded(shapes, seed=555))
+            g.manual_seed(3)
+            model.tap_stores = tuple(tapstore.TapStore(torch.randn(n + 1, 7, d, generator=g, device="cuda") * 0.25, range(7), "cuda", "fp32")
+                                     for d in dims)
+            model.train()
+            loss = model(ids, None, None, lm, None)
+            loss.backward()
+            out[mode] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
+        finally:
+            lib.iisan_set_x3(1)
+    (l0, g0), (l1, g1) = out[0], out[1]
+    assert abs(l1.item() - l0.item()) <= 2e-5 * abs(l0.item()), (l0.item(), l1.item())
+    differ = 0
+    for k in g0:
+        scale = g0[k].abs().max().item() + 1e-20
+        err = (g1[k] - g0[k]).abs().max().item() / scale
+        assert err < 5e-4, (k, err)
+        differ += int(not torch.equal(g0[k], g1[k]))
+    assert differ > 0            # the two routes really are different kernels
