@@ -59,6 +59,9 @@ def parse(argv=None):
     ap.add_argument("--versa", action="store_true",
                     help="with --cached: BASELINE config 5 shapes (IISAN-Versa, ViT-L 1024-wide image taps and Llama-3-70B "
                          "8192-wide text taps, Code_Cached_Asym tap lists) instead of config 3")
+    ap.add_argument("--x3", type=int, default=1, choices=[0, 1, 2],
+                    help="route of the side network's large Linear layers: 1 = product default, 0 = f32 matrix cores only, "
+                         "2 = split-operand fp16 GEMM wherever the shape allows (A/B knob)")
     ap.add_argument("--full-blocks", action="store_true",
                     help="ablation: run every encoder block on every token like HF does (default: the last block computes "
                          "attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed; same taps)")
@@ -418,6 +421,7 @@ def main():
 
     from iisan_amd import _lib
     lib = _lib.load()
+    lib.iisan_set_x3(a.x3)
     if a.cached:
         out = cached_line(a, lib, dev, rank, world, a.steps, a.warmup)
     else:

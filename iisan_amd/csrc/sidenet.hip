@@ -22,6 +22,18 @@
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
                   int nprob, hipStream_t s);
 
+// fused SANB step (sanb.hip)
+struct SanbTowerDesc {
+    const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t D, type;
+    const float* Wd; const float* bd; const float* Wu; const float* bu;
+    float* F; float* U; float* A; float* O;
+    const float* dO; const float* Upre; float* dU; float* dprev; float* da; float* db; float* dgate; float* dbu; float* dbd;
+};
+bool sanb_fused_ok(int D, int down);
+int launch_sanb_fwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s);
+int launch_sanb_bwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s);
+int launch_sanb_transpose(const float* const* in, float* const* out, const int32_t* rows, const int32_t* cols, int n, hipStream_t s);
+
 namespace {
 
 // one tower of one fusion step.  type 0: F = g·a + (1-g)·prev ; type 1: F = prev + g·a + (1-g)·b  (not gated: plain sums)
@@ -172,11 +184,15 @@ struct SideBufs {
     float* dU[3];                    // [M, down]
     float* dDP;                      // [M, d]
     void* x3; size_t x3_bytes;       // scratch of the split-operand GEMM (operand images + scales), null = not used
+    float* WT[3][2];                 // backward of the fused SANB step: Wu^T [64, D] and Wd^T [D, 64] of the current step
 };
 
 // 1 (default): the large Linear layers (fc_z, Versa dim-align; forward, dX and dW) run as split-operand fp16 MFMA GEMMs
 // (split.hip); 0: everything on the f32-input matrix cores (gemm32.hip).  Test / bench knob.
 int g_use_x3 = 1;
+// 1 (default): a SANB step whose active towers share a supported width runs as ONE fused launch per direction (sanb.hip);
+// 0: fusion kernel + separate GEMM launches.  Test / bench knob.
+int g_use_sanb = 1;
 
 size_t x3_need(const Plan& p, int64_t M) {
     if (!g_use_x3) return 0;
@@ -215,6 +231,10 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         b.dU[z] = c.take<float>((size_t)M * p.r);
     }
     b.dDP = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
+    for (int z = 0; z < 3; ++z) {
+        b.WT[z][0] = c.take<float>((size_t)p.D[z] * p.r);
+        b.WT[z][1] = c.take<float>((size_t)p.D[z] * p.r);
+    }
     b.x3_bytes = x3_need(p, M);
     b.x3 = b.x3_bytes ? (void*)c.take<char>(b.x3_bytes) : nullptr;
 }
@@ -294,6 +314,23 @@ struct Ctx {
     }
 };
 
+// the active towers of a step can share one fused launch
+bool step_fusable(const Plan& p, const StepMap& sm) {
+    if (!g_use_sanb) return false;
+    const int D = p.D[sm.z[0]];
+    for (int a = 0; a < sm.nact; ++a)
+        if (p.D[sm.z[a]] != D) return false;
+    return sanb_fused_ok(D, p.r);
+}
+
+void tower_desc(SanbTowerDesc& d, const Ctx& c, int z, int k, const StepMap& sm) {
+    FuseTower ft{};
+    c.fuse_operands(ft, z, k, sm);
+    d = SanbTowerDesc{};
+    d.a = ft.a; d.b = ft.b; d.prev = ft.prev; d.lda = ft.lda; d.ldb = ft.ldb; d.ldp = ft.ldp; d.gate = ft.gate;
+    d.D = ft.D; d.type = ft.type;
+}
+
 int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
           const void* const* params, void* ws, size_t ws_bytes, const char* who) {
     IISAN_CHECK_SHAPE(M > 0, "side_net: M must be positive");
@@ -311,12 +348,14 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 
 }  // namespace
 
+extern "C" void iisan_set_sanb_fused(int32_t on) { g_use_sanb = on; }
+
 void gemm_x3_set_min_flops(double f);
-// 0 = off, 1 = default (products of at least 6 GFLOP), 2 = every product whose shape allows it (tests: the small golden
+// 0 = off, 1 = default (products of at least 150 GFLOP), 2 = every product whose shape allows it (tests: the small golden
 // fixtures then run through the split-operand path too)
 extern "C" void iisan_set_x3(int32_t mode) {
     g_use_x3 = mode != 0;
-    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 6e9);
+    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 1.5e11);
 }
 
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {
@@ -350,6 +389,17 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
                                  b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
             IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
+        }
+        if (step_fusable(p, sm)) {            // fusion + down + activation + up of every active tower in one launch
+            SanbTowerDesc td[3];
+            for (int a = 0; a < sm.nact; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                tower_desc(td[a], c, z, k, sm);
+                td[a].Wd = c.W(p.wd(z, k)); td[a].bd = c.W(p.wd(z, k) + 1); td[a].Wu = c.W(p.wd(z, k) + 2); td[a].bu = c.W(p.wd(z, k) + 3);
+                td[a].F = b.F[k][z]; td[a].U = b.U[k][z]; td[a].A = b.A[k][z]; td[a].O = b.O[k][z];
+            }
+            IISAN_TRY(launch_sanb_fwd(td, sm.nact, M, cfg->gelu, s));
+            continue;
         }
         FuseArgs fa{};
         fa.M = M;
@@ -413,6 +463,36 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     for (int g = nsteps - 1; g >= 0; --g) {
         const StepMap sm = step_map(p, g);
         const int na = sm.nact;
+        if (step_fusable(p, sm) && !(sm.mm_i >= 0 && p.align)) {
+            // dWu += dO^T · A first (needs dO as it arrives), then ONE launch turns dO into dprev in place (tile-local:
+            // a workgroup reads its rows of dO into LDS before it writes them) and leaves dU, db_u, db_d, dθ; dWd += dU^T · F last
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                pr[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);
+            }
+            IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));
+            const float* tin[6]; float* tout[6]; int32_t trows[6], tcols[6];
+            SanbTowerDesc td[3];
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                tin[2 * a] = c.W(p.wd(z, k) + 2); tout[2 * a] = b.WT[z][0]; trows[2 * a] = p.D[z]; tcols[2 * a] = r;         // Wu [D,64] -> [64,D]
+                tin[2 * a + 1] = c.W(p.wd(z, k)); tout[2 * a + 1] = b.WT[z][1]; trows[2 * a + 1] = r; tcols[2 * a + 1] = p.D[z];  // Wd [64,D] -> [D,64]
+                tower_desc(td[a], c, z, k, sm);
+                td[a].Wd = b.WT[z][0]; td[a].Wu = b.WT[z][1];
+                td[a].dO = b.dO[z]; td[a].Upre = b.U[k][z]; td[a].dU = b.dU[z];
+                td[a].dprev = k > 0 ? b.dO[z] : nullptr;     // block 0 starts from zeros / a tap: nobody reads that gradient
+                td[a].dgate = cfg->gated ? G(p.gate(z, k)) : nullptr;
+                td[a].dbu = G(p.wd(z, k) + 3); td[a].dbd = G(p.wd(z, k) + 1);
+            }
+            IISAN_TRY(launch_sanb_transpose(tin, tout, trows, tcols, 2 * na, s));
+            IISAN_TRY(launch_sanb_bwd(td, na, M, cfg->gelu, s));
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                pr[a] = prob(b.dU[z], r, b.F[k][z], p.D[z], nullptr, G(p.wd(z, k)), p.D[z], r, p.D[z], M);
+            }
+            IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWd += dU^T · F
+            continue;
+        }
         // state = A Wu^T + bu + F ; A = act(U) ; U = F Wd^T + bd
         for (int a = 0; a < na; ++a) {
             const int z = sm.z[a], k = sm.k[a];

@@ -169,8 +169,11 @@ static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
     if (p.resid && (p.ldr != p.ldc)) return false;
     return true;
 }
-// below this many FLOPs the four extra small launches (amax + split per operand) cost more than the matrix rate gains
-static double g_x3_min_flops = 6e9;
+// Below this many FLOPs the extra passes (amax + split per operand, split-K atomics) cost more than the matrix rate
+// gains.  Measured (tools/x3_time.py, MI355X): gemm32 reaches 75-118 TF on these shapes; this front end with the 128x128
+// GEMM kernel only wins from ~1.5e11 FLOP ([11264, 8192] x [8192, 1024]: 1.33x) — every product of the benched
+// configurations stays on the f32 matrix cores until the operand images are produced by the upstream kernels.
+static double g_x3_min_flops = 1.5e11;
 void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f; }
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
     return x3_shape_ok(p, flags) && 2.0 * (double)p.M * (double)p.N * (double)p.K >= g_x3_min_flops;

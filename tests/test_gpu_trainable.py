@@ -70,18 +70,28 @@ def test_gemm32_vs_torch(lib, case):
 
 
 @pytest.fixture
+def sanb_mode(lib, request):
+    """1 = product default: a SANB step runs as one fused launch per direction (`csrc/sanb.hip`); 0 = fusion kernel + separate
+    GEMM launches."""
+    lib.iisan_set_sanb_fused(request.param)
+    yield request.param
+    lib.iisan_set_sanb_fused(1)
+
+
+@pytest.fixture
 def x3_mode(lib, request):
     """Route of the side network's large Linear layers (`csrc/sidenet.hip:gemm_group`): 1 = product default (split-operand
-    fp16 MFMA GEMM for products of >= 6 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
+    fp16 MFMA GEMM only for products of >= 150 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
     shape allows it — so the small reference goldens pin that path too — 0 = f32 matrix cores only."""
     lib.iisan_set_x3(request.param)
     yield request.param
     lib.iisan_set_x3(1)
 
 
+@pytest.mark.parametrize("sanb_mode", [1, 0], indirect=True)
 @pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("variant", ["default", "gelu", "rmfirst"])
-def test_cached_model_loss_and_grads_match_reference(variant, x3_mode):
+def test_cached_model_loss_and_grads_match_reference(variant, x3_mode, sanb_mode):
     z, b, taps_cv, taps_tx, P, kw = gio.sidenet_full_inputs(variant)
     args = helpers.make_args(adapter_activation="GELU" if variant == "gelu" else "RELU",
                              remove_first="TRUE" if variant == "rmfirst" else "None")
@@ -737,12 +747,15 @@ def test_out_of_range_ids_are_loud_not_wild_reads():
     assert ranks[0] >= 1 and ranks[1] == -1 and ranks[2] == -1
 
 
+@pytest.mark.parametrize("route", ["x3", "sanb"])
 @pytest.mark.parametrize("versa", [False, True])
-def test_split_operand_layers_at_bench_size_equal_the_f32_matrix_core_path(lib, versa):
-    """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128) the product routes the
-    large Linear layers through the split-operand GEMM.  Same step with that route switched off (every product on the
-    exact-fp32 matrix cores): loss within 2e-5, every gradient within 5e-4 of its scale — the tolerances the small
-    fixtures hold against the reference."""
+def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route):
+    """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128): the same step through
+    (a) the split-operand fp16 GEMM forced onto every large Linear layer ("x3") and (b) the fused one-launch SANB step
+    ("sanb", the product default where the towers' widths allow) against the plain route — separate fusion kernels and
+    f32-matrix-core GEMMs, the path the small fixtures pin to the reference.  Loss within 2e-5, every gradient within 5e-4
+    of its scale.  GELU adapters: with ReLU a 1e-7 difference in a pre-activation near zero flips a unit and moves single
+    gradients by 1e-3 whatever the kernels do (seen on `down_project_list.0`)."""
     from iisan_amd import tapstore
     n = 2000
     bs = 128 if versa else 1024
@@ -750,16 +763,18 @@ def test_split_operand_layers_at_bench_size_equal_the_f32_matrix_core_path(lib, 
     ids, lm = b.ids.view(-1).cuda(), b.log_mask.cuda()
     g = torch.Generator(device="cuda").manual_seed(3)
     out = {}
-    for mode in (0, 1):
-        lib.iisan_set_x3(mode)
+    for alt in (False, True):
+        lib.iisan_set_x3(2 if (alt and route == "x3") else 0)
+        lib.iisan_set_sanb_fused(1 if (alt and route == "sanb") else 0)
         try:
+            kw = dict(drop_rate=0.0, adapter_activation="GELU")
             if versa:
                 args = helpers.make_args(text_embedding_dim=8192, image_embedding_dim=1024, side_adapter_vit_list="3,7,11,15,19,23",
-                                         side_adapter_bert_list="4,19,34,49,64,79", image_layers=24, text_layers=80, drop_rate=0.0)
+                                         side_adapter_bert_list="4,19,34,49,64,79", image_layers=24, text_layers=80, **kw)
                 model = helpers.build_model(args, n, b.pop_prob, cached="versa")
                 dims = (1024, 8192)
             else:
-                args = helpers.make_args(drop_rate=0.0)
+                args = helpers.make_args(**kw)
                 model = helpers.build_model(args, n, b.pop_prob, cached=True)
                 dims = (768, 768)
             shapes = {k: tuple(p.shape) for k, p in model.named_parameters() if p.requires_grad}
@@ -770,10 +785,11 @@ def test_split_operand_layers_at_bench_size_equal_the_f32_matrix_core_path(lib, 
             model.train()
             loss = model(ids, None, None, lm, None)
             loss.backward()
-            out[mode] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
+            out[alt] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
         finally:
             lib.iisan_set_x3(1)
-    (l0, g0), (l1, g1) = out[0], out[1]
+            lib.iisan_set_sanb_fused(1)
+    (l0, g0), (l1, g1) = out[False], out[True]
     assert abs(l1.item() - l0.item()) <= 2e-5 * abs(l0.item()), (l0.item(), l1.item())
     differ = 0
     for k in g0:
@@ -781,4 +797,5 @@ def test_split_operand_layers_at_bench_size_equal_the_f32_matrix_core_path(lib, 
         err = (g1[k] - g0[k]).abs().max().item() / scale
         assert err < 5e-4, (k, err)
         differ += int(not torch.equal(g0[k], g1[k]))
-    assert differ > 0            # the two routes really are different kernels
+    if not (versa and route == "sanb"):      # Versa's towers have different widths: no fused step there (yet)
+        assert differ > 0                    # the two routes really are different kernels
