@@ -23,34 +23,36 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int R = 32;              // rows per tile
 constexpr int RD = 64;             // adapter bottleneck (cfg->down)
-constexpr int UST = RD + 4;        // LDS row stride of the [32, 64] buffers
+constexpr int UST = RD + 1;        // LDS row stride of the [32, 64] buffers (odd: conflict-free column reads)
 
 __device__ __forceinline__ float gate_of(const float* theta) { return 1.0f / (1.0f + __expf(-theta[0] / 0.1f)); }
 __device__ __forceinline__ f16v mfma32(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 // C/D layout of the 32x32 MFMA: register r of lane l is row crow(r, l), column l & 31
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// acc[32, 32] += X[32, K-range] · W[32 rows n0.., K-range]^T, X in LDS (row stride xs floats), W rows in global memory
-// (row stride ws floats, contiguous along k).  K-range = [k0, k0 + 8*groups).
+// acc[32, 32] += X[32, k0 .. k0+nk) · B[k0 .. k0+nk, n0 .. n0+32):  X in LDS (row stride xs floats, odd), B K-MAJOR in
+// global memory (row k at B + k*ldb, columns contiguous): a wave's load of one MFMA operand is two full 128-byte lines.
+// (A first version took 16-byte fragments along k from an N-major matrix — 64 cache lines per load instruction: the
+// kernel ran 5x off the matrix rate.)  PD loads in flight.
 template <int PD>
-__device__ __forceinline__ void mma_k(f16v& acc, const float* __restrict__ Xs, int xs, const float* __restrict__ Wrow, int k0,
-                                      int groups, int lane) {
+__device__ __forceinline__ void mma_kmajor(f16v& acc, const float* __restrict__ Xs, int xs, const float* __restrict__ B,
+                                           int64_t ldb, int n0, int k0, int nk, int lane) {
     const int i = lane & 31, kk = lane >> 5;
-    const float* xp = Xs + i * xs + k0 + 4 * kk;
-    const float* wp = Wrow + k0 + 4 * kk;
-    f4 b[PD];
+    const float* xp = Xs + i * xs + k0 + kk;
+    const float* bp = B + (int64_t)(k0 + kk) * ldb + n0 + i;
+    const int steps = nk / 2;
+    float b[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p)
-        if (p < groups) b[p] = *(const f4*)(wp + 8 * p);
-    for (int g = 0; g < groups; g += PD) {
+        if (p < steps) b[p] = bp[(int64_t)(2 * p) * ldb];
+    for (int st = 0; st < steps; st += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
-            if (g + p < groups) {
-                const f4 a = *(const f4*)(xp + 8 * (g + p));
-                const f4 bb = b[p];
-                if (g + p + PD < groups) b[p] = *(const f4*)(wp + 8 * (g + p + PD));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma32(a[e], bb[e], acc);
+            if (st + p < steps) {
+                const float a = xp[2 * (st + p)];
+                const float bb = b[p];
+                if (st + p + PD < steps) b[p] = bp[(int64_t)(2 * (st + p + PD)) * ldb];
+                acc = mfma32(a, bb, acc);
             }
         }
     }
@@ -62,8 +64,8 @@ struct SanbTower {
     int64_t lda, ldb, ldp;
     const float* gate;
     int32_t D, type;
-    const float* Wd; const float* bd;        // fwd: fc_down [64, D], [64]        bwd: Wu^T [64, D]
-    const float* Wu; const float* bu;        // fwd: fc_up   [D, 64], [D]         bwd: Wd^T [D, 64]
+    const float* Wd; const float* bd;        // fwd: fc_down^T [D, 64], [64]      bwd: fc_up   [D, 64]  (both K-major for the narrow product)
+    const float* Wu; const float* bu;        // fwd: fc_up^T   [64, D], [D]       bwd: fc_down [64, D]  (K-major for the wide product)
     float* F; float* U; float* A; float* O;  // fwd outputs: [M,D] [M,64] [M,64] [M,D]
     // backward
     const float* dO; const float* Upre;      // [M,D] gradient wrt O ; saved pre-activation [M,64]
@@ -77,21 +79,39 @@ struct SanbArgs {
     int32_t gelu;
 };
 
+// LDS: tile [32][D+1] | 4 K-split partial products [4][32][65] | [32][65]
+__host__ __device__ constexpr int lds_floats(int D) { return (R * (D + 1) + 3) / 4 * 4 + 5 * R * UST; }
+
+// narrow product  P[kq] = X[32, quarter kq of D] · B[quarter, 64]  (wave = column fragment nf x K quarter kq); the four
+// partial products are summed in a FIXED order by the caller: bit-reproducible (LDS float atomics were not)
+template <int NF>
+__device__ __forceinline__ void narrow_product(const float* Xs, float* Ps, const float* B, int wave, int lane) {
+    constexpr int D = NF * 256, FS = D + 1;
+    const int nf = wave >> 2, kq = wave & 3;
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mma_kmajor<12>(acc, Xs, FS, B, RD, nf * 32, kq * (D / 4), D / 4, lane);
+    float* P = Ps + kq * R * UST;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[crow(r, lane) * UST + nf * 32 + (lane & 31)] = acc[r];
+}
+
 template <int NF>      // NF = D / 256 column fragments per wave in the wide product
 __global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SanbTower& t = args.t[blockIdx.y];
-    const int D = NF * 256, FS = D + 4;
-    float* Fs = smem;                       // [32][D + 4]
-    float* Us = Fs + R * FS;                // [32][68]  sum of the K-split partial products
-    float* As = Us + R * UST;               // [32][68]  act(U)
+    constexpr int D = NF * 256, FS = D + 1;
+    float* Fs = smem;                                   // [32][D + 1]
+    float* Ps = smem + (R * FS + 3) / 4 * 4;            // [4][32][65]
+    float* As = Ps + 4 * R * UST;                       // [32][65]  act(U)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
     // ---- 1. fused input tile -> LDS and HBM -------------------------------------------------------------------
-    const int d4 = D / 4;
+    constexpr int d4 = D / 4;
     for (int idx = tid; idx < R * d4; idx += 512) {
         const int row = idx / d4, c = (idx - row * d4) * 4;
         const int64_t m = m0 + row;
@@ -108,36 +128,27 @@ __global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
             }
             *(f4*)(t.F + m * D + c) = o;
         }
-        *(f4*)(Fs + row * FS + c) = o;
+        float* fp = Fs + row * FS + c;
+        fp[0] = o[0]; fp[1] = o[1]; fp[2] = o[2]; fp[3] = o[3];
     }
-    for (int idx = tid; idx < R * UST; idx += 512) Us[idx] = 0.f;
     __syncthreads();
 
-    // ---- 2. U = F · Wd^T : wave = (column fragment nf, K quarter kq); partial sums meet in LDS --------------------
-    {
-        const int nf = wave >> 2, kq = wave & 3;
-        f16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_k<4>(acc, Fs, FS, t.Wd + (int64_t)(nf * 32 + (lane & 31)) * D, kq * (D / 4), D / 32, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(Us + crow(r, lane) * UST + nf * 32 + (lane & 31), acc[r]);
-    }
+    // ---- 2. U = F · Wd^T ---------------------------------------------------------------------------------------
+    narrow_product<NF>(Fs, Ps, t.Wd, wave, lane);
     __syncthreads();
 
     // ---- 3. bias, activation; U (pre-activation) and A to HBM, A to LDS ------------------------------------------
     {
         const int row = tid >> 4, c = (tid & 15) * 4;
         const int64_t m = m0 + row;
-        f4 u = *(const f4*)(Us + row * UST + c);
-        const f4 bd = *(const f4*)(t.bd + c);
-        f4 a;
+        f4 u, a;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            u[e] += bd[e];
+            const float* p = Ps + row * UST + c + e;
+            u[e] = ((p[0] + p[R * UST]) + p[2 * R * UST]) + p[3 * R * UST] + t.bd[c + e];
             a[e] = args.gelu ? gelu_erf(u[e]) : fmaxf(u[e], 0.f);
+            As[row * UST + c + e] = a[e];
         }
-        *(f4*)(As + row * UST + c) = a;
         if (m < args.M) {
             *(f4*)(t.U + m * RD + c) = u;
             *(f4*)(t.A + m * RD + c) = a;
@@ -148,12 +159,12 @@ __global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
     // ---- 4. O = A · Wu^T + bu + F : wave owns D/8 columns = NF fragments ------------------------------------------
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const int n = wave * (D / 8) + 32 * f + (lane & 31);
+        const int n0 = wave * (D / 8) + 32 * f, n = n0 + (lane & 31);
         f16v acc;
         const float bu = t.bu[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = Fs[crow(r, lane) * FS + n] + bu;
-        mma_k<8>(acc, As, UST, t.Wu + (int64_t)n * RD, 0, RD / 8, lane);
+        mma_kmajor<16>(acc, As, UST, t.Wu, D, n0, 0, RD, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + crow(r, lane);
@@ -162,77 +173,66 @@ __global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
     }
 }
 
-// backward of one step.  t.Wd = Wu^T [64, D], t.Wu = Wd^T [D, 64] (transposed copies made by sanb_transpose_kernel)
+// backward of one step.  t.Wd = fc_up [D, 64] (K-major for dA = dO · Wu), t.Wu = fc_down [64, D] (K-major for dU · Wd)
 template <int NF>
 __global__ __launch_bounds__(512) void sanb_bwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[8];
     const SanbTower& t = args.t[blockIdx.y];
-    const int D = NF * 256, FS = D + 4;
-    float* Gs = smem;                       // [32][D + 4]  dO tile
-    float* Us = Gs + R * FS;                // [32][68]     dA partial sums
-    float* Ds = Us + R * UST;               // [32][68]     act'(U), then dU
+    constexpr int D = NF * 256, FS = D + 1;
+    float* Gs = smem;                                   // [32][D + 1]  dO tile
+    float* Ps = smem + (R * FS + 3) / 4 * 4;            // [4][32][65]  K-split partial products of dA
+    float* Ds = Ps + 4 * R * UST;                       // [32][65]     act'(U), then dU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
     // ---- 1. dO tile -> LDS ; act'(U) -> LDS ---------------------------------------------------------------------
-    const int d4 = D / 4;
+    constexpr int d4 = D / 4;
     for (int idx = tid; idx < R * d4; idx += 512) {
         const int row = idx / d4, c = (idx - row * d4) * 4;
         const int64_t m = m0 + row;
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < args.M) v = *(const f4*)(t.dO + m * D + c);
-        *(f4*)(Gs + row * FS + c) = v;
+        float* gp = Gs + row * FS + c;
+        gp[0] = v[0]; gp[1] = v[1]; gp[2] = v[2]; gp[3] = v[3];
     }
     {
         const int row = tid >> 4, c = (tid & 15) * 4;
         const int64_t m = m0 + row;
-        f4 d = {0.f, 0.f, 0.f, 0.f};
-        if (m < args.M) {
-            const f4 u = *(const f4*)(t.Upre + m * RD + c);
+        f4 u = {0.f, 0.f, 0.f, 0.f};
+        if (m < args.M) u = *(const f4*)(t.Upre + m * RD + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = args.gelu ? gelu_erf_grad(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
-        }
-        *(f4*)(Ds + row * UST + c) = d;
-        *(f4*)(Us + row * UST + c) = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e)
+            Ds[row * UST + c + e] = (m < args.M) ? (args.gelu ? gelu_erf_grad(u[e]) : (u[e] > 0.f ? 1.f : 0.f)) : 0.f;
     }
     __syncthreads();
 
-    // db_u += colsum(dO): one thread per column quad
-    if (t.dbu && tid < d4) {
-        f4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int row = 0; row < R; ++row) {
-            const f4 v = *(const f4*)(Gs + row * FS + tid * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += v[e];
+    // db_u += colsum(dO): one thread per column, fixed row order
+    if (t.dbu) {
+        for (int c = tid; c < D; c += 512) {
+            float s = 0.f;
+            for (int row = 0; row < R; ++row) s += Gs[row * FS + c];
+            unsafeAtomicAdd(t.dbu + c, s);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(t.dbu + tid * 4 + e, s[e]);
     }
 
-    // ---- 2. dA = dO · Wu  (B rows = Wu^T [64, D]) ---------------------------------------------------------------
-    {
-        const int nf = wave >> 2, kq = wave & 3;
-        f16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_k<4>(acc, Gs, FS, t.Wd + (int64_t)(nf * 32 + (lane & 31)) * D, kq * (D / 4), D / 32, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(Us + crow(r, lane) * UST + nf * 32 + (lane & 31), acc[r]);
-    }
+    // ---- 2. dA = dO · Wu ----------------------------------------------------------------------------------------
+    narrow_product<NF>(Gs, Ps, t.Wd, wave, lane);
     __syncthreads();
 
     // ---- 3. dU = dA ⊙ act'(U) -> LDS and HBM ; db_d += colsum(dU) -------------------------------------------------
     {
         const int row = tid >> 4, c = (tid & 15) * 4;
         const int64_t m = m0 + row;
-        const f4 da = *(const f4*)(Us + row * UST + c);
-        f4 du = *(const f4*)(Ds + row * UST + c);
+        f4 du;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) du[e] *= da[e];
-        *(f4*)(Ds + row * UST + c) = du;          // same thread wrote act'(U) here: no hazard
+        for (int e = 0; e < 4; ++e) {
+            const float* p = Ps + row * UST + c + e;
+            du[e] = (((p[0] + p[R * UST]) + p[2 * R * UST]) + p[3 * R * UST]) * Ds[row * UST + c + e];
+            Ds[row * UST + c + e] = du[e];            // the same thread wrote act'(U) here: no hazard
+        }
         if (m < args.M) *(f4*)(t.dU + m * RD + c) = du;
     }
     __syncthreads();
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(512) void sanb_bwd_kernel(SanbArgs args) {
     const float ca = gated ? g : 1.f, cb = gated ? 1.f - g : 1.f;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const int n = wave * (D / 8) + 32 * f + (lane & 31);
+        const int n0 = wave * (D / 8) + 32 * f, n = n0 + (lane & 31);
         f16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = Gs[crow(r, lane) * FS + n];
-        mma_k<8>(acc, Ds, UST, t.Wu + (int64_t)n * RD, 0, RD / 8, lane);
+        mma_kmajor<16>(acc, Ds, UST, t.Wu, D, n0, 0, RD, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + crow(r, lane);
@@ -298,12 +298,12 @@ __global__ __launch_bounds__(256) void sanb_transpose_kernel(TransArgs a) {
         if (c0 + j < cols && r0 + tx < rows) a.out[z][(int64_t)(c0 + j) * rows + r0 + tx] = T[tx][j];
 }
 
-size_t lds_bytes(int D) { return (size_t)(R * (D + 4) + 2 * R * UST) * sizeof(float); }
+size_t lds_bytes(int D) { return (size_t)lds_floats(D) * sizeof(float); }
 
 }  // namespace
 
 // ---- host interface (sidenet.hip) -------------------------------------------------------------------------------
-bool sanb_fused_ok(int D, int down) { return down == RD && (D == 768 || D == 1024 || D == 512 || D == 256); }
+bool sanb_fused_ok(int D, int down) { return down == RD && (D == 768 || D == 512 || D == 256); }
 
 struct SanbTowerDesc {       // plain-pointer mirror of SanbTower for the executor
     const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t D, type;
@@ -344,7 +344,6 @@ static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, 
         case 256: SANB_LAUNCH(1); break;
         case 512: SANB_LAUNCH(2); break;
         case 768: SANB_LAUNCH(3); break;
-        case 1024: SANB_LAUNCH(4); break;
         default: iisan_set_error("sanb: width %d", D); return IISAN_EBADSHAPE;
     }
 #undef SANB_LAUNCH

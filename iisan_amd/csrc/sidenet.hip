@@ -392,12 +392,16 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
         }
         if (step_fusable(p, sm)) {            // fusion + down + activation + up of every active tower in one launch
             SanbTowerDesc td[3];
+            const float* tin[6]; float* tout[6]; int32_t trows[6], tcols[6];
             for (int a = 0; a < sm.nact; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
+                tin[2 * a] = c.W(p.wd(z, k)); tout[2 * a] = b.WT[z][0]; trows[2 * a] = p.r; tcols[2 * a] = p.D[z];              // fc_down [64,D] -> [D,64]
+                tin[2 * a + 1] = c.W(p.wd(z, k) + 2); tout[2 * a + 1] = b.WT[z][1]; trows[2 * a + 1] = p.D[z]; tcols[2 * a + 1] = p.r;  // fc_up [D,64] -> [64,D]
                 tower_desc(td[a], c, z, k, sm);
-                td[a].Wd = c.W(p.wd(z, k)); td[a].bd = c.W(p.wd(z, k) + 1); td[a].Wu = c.W(p.wd(z, k) + 2); td[a].bu = c.W(p.wd(z, k) + 3);
+                td[a].Wd = b.WT[z][0]; td[a].bd = c.W(p.wd(z, k) + 1); td[a].Wu = b.WT[z][1]; td[a].bu = c.W(p.wd(z, k) + 3);
                 td[a].F = b.F[k][z]; td[a].U = b.U[k][z]; td[a].A = b.A[k][z]; td[a].O = b.O[k][z];
             }
+            IISAN_TRY(launch_sanb_transpose(tin, tout, trows, tcols, 2 * sm.nact, s));
             IISAN_TRY(launch_sanb_fwd(td, sm.nact, M, cfg->gelu, s));
             continue;
         }
@@ -471,20 +475,16 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
                 pr[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);
             }
             IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));
-            const float* tin[6]; float* tout[6]; int32_t trows[6], tcols[6];
             SanbTowerDesc td[3];
             for (int a = 0; a < na; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
-                tin[2 * a] = c.W(p.wd(z, k) + 2); tout[2 * a] = b.WT[z][0]; trows[2 * a] = p.D[z]; tcols[2 * a] = r;         // Wu [D,64] -> [64,D]
-                tin[2 * a + 1] = c.W(p.wd(z, k)); tout[2 * a + 1] = b.WT[z][1]; trows[2 * a + 1] = r; tcols[2 * a + 1] = p.D[z];  // Wd [64,D] -> [D,64]
                 tower_desc(td[a], c, z, k, sm);
-                td[a].Wd = b.WT[z][0]; td[a].Wu = b.WT[z][1];
+                td[a].Wd = c.W(p.wd(z, k) + 2); td[a].Wu = c.W(p.wd(z, k));      // fc_up [D,64] and fc_down [64,D] as stored: K-major for the backward products
                 td[a].dO = b.dO[z]; td[a].Upre = b.U[k][z]; td[a].dU = b.dU[z];
                 td[a].dprev = k > 0 ? b.dO[z] : nullptr;     // block 0 starts from zeros / a tap: nobody reads that gradient
                 td[a].dgate = cfg->gated ? G(p.gate(z, k)) : nullptr;
                 td[a].dbu = G(p.wd(z, k) + 3); td[a].dbd = G(p.wd(z, k) + 1);
             }
-            IISAN_TRY(launch_sanb_transpose(tin, tout, trows, tcols, 2 * na, s));
             IISAN_TRY(launch_sanb_bwd(td, na, M, cfg->gelu, s));
             for (int a = 0; a < na; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
