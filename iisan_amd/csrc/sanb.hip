@@ -19,44 +19,15 @@
 
 namespace {
 
-typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int R = 32;              // rows per tile
+constexpr int R = 16;              // rows per tile
 constexpr int RD = 64;             // adapter bottleneck (cfg->down)
-constexpr int UST = RD + 1;        // LDS row stride of the [32, 64] buffers (odd: conflict-free column reads)
+constexpr int UST = RD + 2;        // LDS row stride of the [16, 64] buffer; stride % 32 == 2: conflict-free A-operand reads
+constexpr int NT = 256;            // threads per workgroup (4 waves), three workgroups per CU (LDS: 3 x 53.5 KB)
 
 __device__ __forceinline__ float gate_of(const float* theta) { return 1.0f / (1.0f + __expf(-theta[0] / 0.1f)); }
-__device__ __forceinline__ f16v mfma32(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-// C/D layout of the 32x32 MFMA: register r of lane l is row crow(r, l), column l & 31
-__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-// acc[32, 32] += X[32, k0 .. k0+nk) · B[k0 .. k0+nk, n0 .. n0+32):  X in LDS (row stride xs floats, odd), B K-MAJOR in
-// global memory (row k at B + k*ldb, columns contiguous): a wave's load of one MFMA operand is two full 128-byte lines.
-// (A first version took 16-byte fragments along k from an N-major matrix — 64 cache lines per load instruction: the
-// kernel ran 5x off the matrix rate.)  PD loads in flight.
-template <int PD>
-__device__ __forceinline__ void mma_kmajor(f16v& acc, const float* __restrict__ Xs, int xs, const float* __restrict__ B,
-                                           int64_t ldb, int n0, int k0, int nk, int lane) {
-    const int i = lane & 31, kk = lane >> 5;
-    const float* xp = Xs + i * xs + k0 + kk;
-    const float* bp = B + (int64_t)(k0 + kk) * ldb + n0 + i;
-    const int steps = nk / 2;
-    float b[PD];
-#pragma unroll
-    for (int p = 0; p < PD; ++p)
-        if (p < steps) b[p] = bp[(int64_t)(2 * p) * ldb];
-    for (int st = 0; st < steps; st += PD) {
-#pragma unroll
-        for (int p = 0; p < PD; ++p) {
-            if (st + p < steps) {
-                const float a = xp[2 * (st + p)];
-                const float bb = b[p];
-                if (st + p + PD < steps) b[p] = bp[(int64_t)(2 * (st + p + PD)) * ldb];
-                acc = mfma32(a, bb, acc);
-            }
-        }
-    }
-}
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// v_mfma_f32_16x16x4_f32: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C/D register r = row 4*(l>>4)+r, column l&15
 
 struct SanbTower {
     // fusion operands (sidenet.hip FuseTower): type 0: F = g·a + (1-g)·prev ; type 1: F = prev + g·a + (1-g)·b ; no gate: sums
@@ -64,7 +35,7 @@ struct SanbTower {
     int64_t lda, ldb, ldp;
     const float* gate;
     int32_t D, type;
-    const float* Wd; const float* bd;        // fwd: fc_down^T [D, 64], [64]      bwd: fc_up   [D, 64]  (both K-major for the narrow product)
+    const float* Wd; const float* bd;        // fwd: fc_down^T [D, 64], [64]      bwd: fc_up   [D, 64]  (K-major for the narrow product)
     const float* Wu; const float* bu;        // fwd: fc_up^T   [64, D], [D]       bwd: fc_down [64, D]  (K-major for the wide product)
     float* F; float* U; float* A; float* O;  // fwd outputs: [M,D] [M,64] [M,64] [M,D]
     // backward
@@ -79,40 +50,76 @@ struct SanbArgs {
     int32_t gelu;
 };
 
-// LDS: tile [32][D+1] | 4 K-split partial products [4][32][65] | [32][65]
-__host__ __device__ constexpr int lds_floats(int D) { return (R * (D + 1) + 3) / 4 * 4 + 5 * R * UST; }
+// LDS: tile [16][D+2] | [16][66]
+__host__ __device__ constexpr int lds_floats(int D) { return R * (D + 2) + R * UST; }
 
-// narrow product  P[kq] = X[32, quarter kq of D] · B[quarter, 64]  (wave = column fragment nf x K quarter kq); the four
-// partial products are summed in a FIXED order by the caller: bit-reproducible (LDS float atomics were not)
-template <int NF>
-__device__ __forceinline__ void narrow_product(const float* Xs, float* Ps, const float* B, int wave, int lane) {
-    constexpr int D = NF * 256, FS = D + 1;
-    const int nf = wave >> 2, kq = wave & 3;
-    f16v acc;
+// narrow product: returns this wave's 16 x 16 fragment (columns 16*wave ..) of  X[16, D] · B[D, 64],  X in LDS (row stride
+// FS), B K-major in global memory (row k = 64 contiguous floats: a quarter-wave reads one 64-byte segment per MFMA operand).
+// Full K per wave: no partial sums to combine, bit-reproducible.  Two accumulators break the 40-cycle dependent latency.
+template <int D>
+__device__ __forceinline__ f4 narrow_product(const float* Xs, const float* __restrict__ B, int wave, int lane) {
+    constexpr int FS = D + 2, PD = 16;
+    const float* xp = Xs + (lane & 15) * FS + (lane >> 4);
+    const float* bp = B + (int64_t)(lane >> 4) * RD + wave * 16 + (lane & 15);
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float b[PD];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mma_kmajor<12>(acc, Xs, FS, B, RD, nf * 32, kq * (D / 4), D / 4, lane);
-    float* P = Ps + kq * R * UST;
+    for (int p = 0; p < PD; ++p) b[p] = bp[(int64_t)(4 * p) * RD];
+    for (int k0 = 0; k0 < D; k0 += 4 * PD) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) P[crow(r, lane) * UST + nf * 32 + (lane & 31)] = acc[r];
+        for (int p = 0; p < PD; ++p) {
+            const float a = xp[k0 + 4 * p];
+            const float bb = b[p];
+            if (k0 + 4 * (p + PD) < D) b[p] = bp[(int64_t)(k0 + 4 * (p + PD)) * RD];
+            if (p & 1) acc1 = mfma16(a, bb, acc1);
+            else acc0 = mfma16(a, bb, acc0);
+        }
+    }
+    return acc0 + acc1;
 }
 
-template <int NF>      // NF = D / 256 column fragments per wave in the wide product
-__global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
+// wide product in place:  T[16, D] += X[16, 64] · B[64, D]  (+ bias), T in LDS (row stride D+2), X in LDS (stride UST), B K-major
+// (row k = D contiguous floats).  A wave owns D/4 columns; fragments go in pairs (independent accumulators).
+template <int D>
+__device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const float* __restrict__ B, const float* __restrict__ bias,
+                                             int wave, int lane) {
+    constexpr int FS = D + 2;
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = Xs[(lane & 15) * UST + 4 * s + (lane >> 4)];
+    const int col = lane & 15, rg = lane >> 4;
+#pragma unroll 1
+    for (int n0 = wave * (D / 4); n0 < (wave + 1) * (D / 4); n0 += 32) {
+        const float* bp = B + (int64_t)rg * D + n0 + col;
+        float b0[16], b1[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { b0[s] = bp[(int64_t)(4 * s) * D]; b1[s] = bp[(int64_t)(4 * s) * D + 16]; }
+        f4 c0, c1;
+        float* t0 = Ts + (4 * rg) * FS + n0 + col;
+        const float bi0 = bias ? bias[n0 + col] : 0.f, bi1 = bias ? bias[n0 + 16 + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c0[r] = t0[r * FS] + bi0; c1[r] = t0[r * FS + 16] + bi1; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { c0 = mfma16(a[s], b0[s], c0); c1 = mfma16(a[s], b1[s], c1); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t0[r * FS] = c0[r]; t0[r * FS + 16] = c1[r]; }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SanbTower& t = args.t[blockIdx.y];
-    constexpr int D = NF * 256, FS = D + 1;
-    float* Fs = smem;                                   // [32][D + 1]
-    float* Ps = smem + (R * FS + 3) / 4 * 4;            // [4][32][65]
-    float* As = Ps + 4 * R * UST;                       // [32][65]  act(U)
+    constexpr int FS = D + 2, d4 = D / 4;
+    float* Fs = smem;                 // [16][D + 2]   F, then O in place
+    float* As = smem + R * FS;        // [16][66]      act(U)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
     // ---- 1. fused input tile -> LDS and HBM -------------------------------------------------------------------
-    constexpr int d4 = D / 4;
-    for (int idx = tid; idx < R * d4; idx += 512) {
+    for (int idx = tid; idx < R * d4; idx += NT) {
         const int row = idx / d4, c = (idx - row * d4) * 4;
         const int64_t m = m0 + row;
         f4 o = {0.f, 0.f, 0.f, 0.f};
@@ -128,157 +135,142 @@ __global__ __launch_bounds__(512) void sanb_fwd_kernel(SanbArgs args) {
             }
             *(f4*)(t.F + m * D + c) = o;
         }
-        float* fp = Fs + row * FS + c;
-        fp[0] = o[0]; fp[1] = o[1]; fp[2] = o[2]; fp[3] = o[3];
+        f2* fp = (f2*)(Fs + row * FS + c);        // rows are 8-byte aligned (FS even)
+        fp[0] = (f2){o[0], o[1]};
+        fp[1] = (f2){o[2], o[3]};
     }
     __syncthreads();
 
-    // ---- 2. U = F · Wd^T ---------------------------------------------------------------------------------------
-    narrow_product<NF>(Fs, Ps, t.Wd, wave, lane);
-    __syncthreads();
-
-    // ---- 3. bias, activation; U (pre-activation) and A to HBM, A to LDS ------------------------------------------
+    // ---- 2. U = F · Wd^T + bd ; A = act(U) : one 16 x 16 fragment per wave -----------------------------------------
     {
-        const int row = tid >> 4, c = (tid & 15) * 4;
-        const int64_t m = m0 + row;
-        f4 u, a;
+        const f4 u4 = narrow_product<D>(Fs, t.Wd, wave, lane);
+        const int col = wave * 16 + (lane & 15);
+        const float bd = t.bd[col];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* p = Ps + row * UST + c + e;
-            u[e] = ((p[0] + p[R * UST]) + p[2 * R * UST]) + p[3 * R * UST] + t.bd[c + e];
-            a[e] = args.gelu ? gelu_erf(u[e]) : fmaxf(u[e], 0.f);
-            As[row * UST + c + e] = a[e];
-        }
-        if (m < args.M) {
-            *(f4*)(t.U + m * RD + c) = u;
-            *(f4*)(t.A + m * RD + c) = a;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            const int64_t m = m0 + row;
+            const float u = u4[r] + bd;
+            const float a = args.gelu ? gelu_erf(u) : fmaxf(u, 0.f);
+            As[row * UST + col] = a;
+            if (m < args.M) {
+                t.U[m * RD + col] = u;
+                t.A[m * RD + col] = a;
+            }
         }
     }
     __syncthreads();
 
-    // ---- 4. O = A · Wu^T + bu + F : wave owns D/8 columns = NF fragments ------------------------------------------
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int n0 = wave * (D / 8) + 32 * f, n = n0 + (lane & 31);
-        f16v acc;
-        const float bu = t.bu[n];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = Fs[crow(r, lane) * FS + n] + bu;
-        mma_kmajor<16>(acc, As, UST, t.Wu, D, n0, 0, RD, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + crow(r, lane);
-            if (m < args.M) t.O[m * D + n] = acc[r];
-        }
+    // ---- 3. O = A · Wu^T + bu + F, in place in LDS -----------------------------------------------------------------
+    wide_product<D>(Fs, As, t.Wu, t.bu, wave, lane);
+    __syncthreads();
+
+    // ---- 4. tile -> HBM, full rows -----------------------------------------------------------------------------------
+    for (int idx = tid; idx < R * d4; idx += NT) {
+        const int row = idx / d4, c = (idx - row * d4) * 4;
+        const int64_t m = m0 + row;
+        if (m >= args.M) continue;
+        const f2* fp = (const f2*)(Fs + row * FS + c);
+        const f2 lo = fp[0], hi = fp[1];
+        *(f4*)(t.O + m * D + c) = (f4){lo[0], lo[1], hi[0], hi[1]};
     }
 }
 
 // backward of one step.  t.Wd = fc_up [D, 64] (K-major for dA = dO · Wu), t.Wu = fc_down [64, D] (K-major for dU · Wd)
-template <int NF>
-__global__ __launch_bounds__(512) void sanb_bwd_kernel(SanbArgs args) {
+template <int D>
+__global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float red[8];
+    __shared__ float red[4];
     const SanbTower& t = args.t[blockIdx.y];
-    constexpr int D = NF * 256, FS = D + 1;
-    float* Gs = smem;                                   // [32][D + 1]  dO tile
-    float* Ps = smem + (R * FS + 3) / 4 * 4;            // [4][32][65]  K-split partial products of dA
-    float* Ds = Ps + 4 * R * UST;                       // [32][65]     act'(U), then dU
+    constexpr int FS = D + 2, d4 = D / 4;
+    float* Gs = smem;                 // [16][D + 2]  dO, then dF in place
+    float* Ds = smem + R * FS;        // [16][66]     dU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
-    // ---- 1. dO tile -> LDS ; act'(U) -> LDS ---------------------------------------------------------------------
-    constexpr int d4 = D / 4;
-    for (int idx = tid; idx < R * d4; idx += 512) {
+    // ---- 1. dO tile -> LDS -----------------------------------------------------------------------------------------
+    for (int idx = tid; idx < R * d4; idx += NT) {
         const int row = idx / d4, c = (idx - row * d4) * 4;
         const int64_t m = m0 + row;
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < args.M) v = *(const f4*)(t.dO + m * D + c);
-        float* gp = Gs + row * FS + c;
-        gp[0] = v[0]; gp[1] = v[1]; gp[2] = v[2]; gp[3] = v[3];
-    }
-    {
-        const int row = tid >> 4, c = (tid & 15) * 4;
-        const int64_t m = m0 + row;
-        f4 u = {0.f, 0.f, 0.f, 0.f};
-        if (m < args.M) u = *(const f4*)(t.Upre + m * RD + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            Ds[row * UST + c + e] = (m < args.M) ? (args.gelu ? gelu_erf_grad(u[e]) : (u[e] > 0.f ? 1.f : 0.f)) : 0.f;
+        f2* gp = (f2*)(Gs + row * FS + c);
+        gp[0] = (f2){v[0], v[1]};
+        gp[1] = (f2){v[2], v[3]};
     }
     __syncthreads();
 
-    // db_u += colsum(dO): one thread per column, fixed row order
+    // db_u += colsum(dO): one thread per column, fixed row order inside the tile
     if (t.dbu) {
-        for (int c = tid; c < D; c += 512) {
+        for (int c = tid; c < D; c += NT) {
             float s = 0.f;
+#pragma unroll
             for (int row = 0; row < R; ++row) s += Gs[row * FS + c];
             unsafeAtomicAdd(t.dbu + c, s);
         }
     }
 
-    // ---- 2. dA = dO · Wu ----------------------------------------------------------------------------------------
-    narrow_product<NF>(Gs, Ps, t.Wd, wave, lane);
-    __syncthreads();
-
-    // ---- 3. dU = dA ⊙ act'(U) -> LDS and HBM ; db_d += colsum(dU) -------------------------------------------------
+    // ---- 2. dU = (dO · Wu) ⊙ act'(U) -> LDS and HBM ------------------------------------------------------------------
     {
-        const int row = tid >> 4, c = (tid & 15) * 4;
-        const int64_t m = m0 + row;
-        f4 du;
+        const f4 da = narrow_product<D>(Gs, t.Wd, wave, lane);
+        const int col = wave * 16 + (lane & 15);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* p = Ps + row * UST + c + e;
-            du[e] = (((p[0] + p[R * UST]) + p[2 * R * UST]) + p[3 * R * UST]) * Ds[row * UST + c + e];
-            Ds[row * UST + c + e] = du[e];            // the same thread wrote act'(U) here: no hazard
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            const int64_t m = m0 + row;
+            float du = 0.f;
+            if (m < args.M) {
+                const float u = t.Upre[m * RD + col];
+                du = da[r] * (args.gelu ? gelu_erf_grad(u) : (u > 0.f ? 1.f : 0.f));
+                t.dU[m * RD + col] = du;
+            }
+            Ds[row * UST + col] = du;
         }
-        if (m < args.M) *(f4*)(t.dU + m * RD + c) = du;
     }
     __syncthreads();
     if (t.dbd && tid < RD) {
         float s = 0.f;
+#pragma unroll
         for (int row = 0; row < R; ++row) s += Ds[row * UST + tid];
         unsafeAtomicAdd(t.dbd + tid, s);
     }
 
-    // ---- 4. dF = dO + dU · Wd ; gate gradient ; dprev -------------------------------------------------------------
+    // ---- 3. dF = dO + dU · Wd, in place in LDS ---------------------------------------------------------------------------
+    wide_product<D>(Gs, Ds, t.Wu, nullptr, wave, lane);
+    __syncthreads();
+
+    // ---- 4. gate gradient, dprev (and the dim-align gradients) with full-row accesses ---------------------------------------
     float part = 0.f;
     const float ca = gated ? g : 1.f, cb = gated ? 1.f - g : 1.f;
+    for (int idx = tid; idx < R * d4; idx += NT) {
+        const int row = idx / d4, c = (idx - row * d4) * 4;
+        const int64_t m = m0 + row;
+        if (m >= args.M) continue;
+        const f2* gp = (const f2*)(Gs + row * FS + c);
+        const f2 lo = gp[0], hi = gp[1];
+        const f4 df = {lo[0], lo[1], hi[0], hi[1]};
+        if (gated) {
+            const f4 av = *(const f4*)(t.a + m * t.lda + c);
+            f4 ov = {0.f, 0.f, 0.f, 0.f};
+            if (t.type == 1) ov = *(const f4*)(t.b + m * t.ldb + c);
+            else if (t.prev) ov = *(const f4*)(t.prev + m * t.ldp + c);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int n0 = wave * (D / 8) + 32 * f, n = n0 + (lane & 31);
-        f16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = Gs[crow(r, lane) * FS + n];
-        mma_kmajor<16>(acc, Ds, UST, t.Wu, D, n0, 0, RD, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + crow(r, lane);
-            if (m >= args.M) continue;
-            const float df = acc[r];
-            if (gated) {
-                const float av = t.a[m * t.lda + n];
-                float ov = 0.f;
-                if (t.type == 1) ov = t.b[m * t.ldb + n];
-                else if (t.prev) ov = t.prev[m * t.ldp + n];
-                part += df * (av - ov);
-            }
-            if (t.da) t.da[m * D + n] = ca * df;
-            if (t.db) t.db[m * D + n] = cb * df;
-            if (t.dprev) t.dprev[m * D + n] = (t.type == 0 && gated) ? cb * df : df;
+            for (int e = 0; e < 4; ++e) part += df[e] * (av[e] - ov[e]);
+        }
+        if (t.da) *(f4*)(t.da + m * D + c) = (f4){ca * df[0], ca * df[1], ca * df[2], ca * df[3]};
+        if (t.db) *(f4*)(t.db + m * D + c) = (f4){cb * df[0], cb * df[1], cb * df[2], cb * df[3]};
+        if (t.dprev) {
+            const float sc = (t.type == 0 && gated) ? cb : 1.f;
+            *(f4*)(t.dprev + m * D + c) = (f4){sc * df[0], sc * df[1], sc * df[2], sc * df[3]};
         }
     }
     if (gated) {
         part = wave_sum(part);
         if (lane == 0) red[wave] = part;
         __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w];
-            atomicAdd(t.dgate, s * g * (1.f - g) / 0.1f);
-        }
+        if (tid == 0) atomicAdd(t.dgate, (red[0] + red[1] + red[2] + red[3]) * g * (1.f - g) / 0.1f);
     }
 }
 
@@ -303,7 +295,7 @@ size_t lds_bytes(int D) { return (size_t)lds_floats(D) * sizeof(float); }
 }  // namespace
 
 // ---- host interface (sidenet.hip) -------------------------------------------------------------------------------
-bool sanb_fused_ok(int D, int down) { return down == RD && (D == 768 || D == 512 || D == 256); }
+bool sanb_fused_ok(int D, int down) { return down == RD && (D == 1024 || D == 768 || D == 512 || D == 256); }
 
 struct SanbTowerDesc {       // plain-pointer mirror of SanbTower for the executor
     const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t D, type;
@@ -328,22 +320,23 @@ static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, 
         IISAN_CHECK_SHAPE(towers[i].D == D && sanb_fused_ok(D, RD), "sanb: towers of one launch must share a supported width");
         fill(a.t[i], towers[i]);
     }
-    const dim3 grid((unsigned)ceil_div(M, R), (unsigned)n), block(512);
+    const dim3 grid((unsigned)ceil_div(M, R), (unsigned)n), block(NT);
     const size_t lds = lds_bytes(D);
-#define SANB_LAUNCH(NF)                                                                                                \
+#define SANB_LAUNCH(DD)                                                                                                \
     do {                                                                                                               \
-        auto k = BWD ? sanb_bwd_kernel<NF> : sanb_fwd_kernel<NF>;                                                      \
+        auto k = BWD ? sanb_bwd_kernel<DD> : sanb_fwd_kernel<DD>;                                                      \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            IISAN_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(NF * 256))); \
+            IISAN_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(DD))); \
             attr_set = true;                                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                                 \
     } while (0)
     switch (D) {
-        case 256: SANB_LAUNCH(1); break;
-        case 512: SANB_LAUNCH(2); break;
-        case 768: SANB_LAUNCH(3); break;
+        case 256: SANB_LAUNCH(256); break;
+        case 512: SANB_LAUNCH(512); break;
+        case 768: SANB_LAUNCH(768); break;
+        case 1024: SANB_LAUNCH(1024); break;
         default: iisan_set_error("sanb: width %d", D); return IISAN_EBADSHAPE;
     }
 #undef SANB_LAUNCH
