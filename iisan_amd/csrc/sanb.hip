@@ -58,7 +58,7 @@ __host__ __device__ constexpr int lds_floats(int D) { return R * (D + 2) + R * U
 // Full K per wave: no partial sums to combine, bit-reproducible.  Two accumulators break the 40-cycle dependent latency.
 template <int D>
 __device__ __forceinline__ f4 narrow_product(const float* Xs, const float* __restrict__ B, int wave, int lane) {
-    constexpr int FS = D + 2, PD = 16;
+    constexpr int FS = D + 2, PD = 32;
     const float* xp = Xs + (lane & 15) * FS + (lane >> 4);
     const float* bp = B + (int64_t)(lane >> 4) * RD + wave * 16 + (lane & 15);
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -88,12 +88,20 @@ __device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const f
 #pragma unroll
     for (int s = 0; s < 16; ++s) a[s] = Xs[(lane & 15) * UST + 4 * s + (lane >> 4)];
     const int col = lane & 15, rg = lane >> 4;
+    const float* bp = B + (int64_t)rg * D + wave * (D / 4) + col;
+    float b0[16], b1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { b0[s] = bp[(int64_t)(4 * s) * D]; b1[s] = bp[(int64_t)(4 * s) * D + 16]; }
 #pragma unroll 1
     for (int n0 = wave * (D / 4); n0 < (wave + 1) * (D / 4); n0 += 32) {
-        const float* bp = B + (int64_t)rg * D + n0 + col;
-        float b0[16], b1[16];
+        // the next pair's weights are requested before this pair's MFMAs: an L2 round trip (~1 us under load) per pair
+        // was otherwise exposed six times per tile
+        float nb0[16], nb1[16];
+        const bool more = n0 + 32 < (wave + 1) * (D / 4);
+        if (more) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { b0[s] = bp[(int64_t)(4 * s) * D]; b1[s] = bp[(int64_t)(4 * s) * D + 16]; }
+            for (int s = 0; s < 16; ++s) { nb0[s] = bp[(int64_t)(4 * s) * D + 32]; nb1[s] = bp[(int64_t)(4 * s) * D + 48]; }
+        }
         f4 c0, c1;
         float* t0 = Ts + (4 * rg) * FS + n0 + col;
         const float bi0 = bias ? bias[n0 + col] : 0.f, bi1 = bias ? bias[n0 + 16 + col] : 0.f;
@@ -103,6 +111,11 @@ __device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const f
         for (int s = 0; s < 16; ++s) { c0 = mfma16(a[s], b0[s], c0); c1 = mfma16(a[s], b1[s], c1); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t0[r * FS] = c0[r]; t0[r * FS + 16] = c1[r]; }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { b0[s] = nb0[s]; b1[s] = nb1[s]; }
+        }
+        bp += 32;
     }
 }
 
@@ -118,26 +131,36 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
-    // ---- 1. fused input tile -> LDS and HBM -------------------------------------------------------------------
-    for (int idx = tid; idx < R * d4; idx += NT) {
-        const int row = idx / d4, c = (idx - row * d4) * 4;
-        const int64_t m = m0 + row;
-        f4 o = {0.f, 0.f, 0.f, 0.f};
-        if (m < args.M) {
-            const f4 av = *(const f4*)(t.a + m * t.lda + c);
-            f4 pv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-            if (t.prev) pv = *(const f4*)(t.prev + m * t.ldp + c);
-            if (t.type == 1) bv = *(const f4*)(t.b + m * t.ldb + c);
+    // ---- 1. fused input tile -> LDS and HBM.  Loads of CH iterations are issued together: one HBM round trip per CH ----
+    constexpr int IT = R * d4 / NT, CH = IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : 1);
+    for (int i0 = 0; i0 < IT; i0 += CH) {
+        f4 av[CH], pv[CH], bv[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = tid + (i0 + j) * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            const int64_t m = m0 + row;
+            av[j] = pv[j] = bv[j] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (m < args.M) {
+                av[j] = *(const f4*)(t.a + m * t.lda + c);
+                if (t.prev) pv[j] = *(const f4*)(t.prev + m * t.ldp + c);
+                if (t.type == 1) bv[j] = *(const f4*)(t.b + m * t.ldb + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = tid + (i0 + j) * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            const int64_t m = m0 + row;
+            f4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (t.type == 0) o[e] = gated ? g * av[e] + (1.f - g) * pv[e] : av[e] + pv[e];
-                else o[e] = gated ? pv[e] + g * av[e] + (1.f - g) * bv[e] : pv[e] + av[e] + bv[e];
+                if (t.type == 0) o[e] = gated ? g * av[j][e] + (1.f - g) * pv[j][e] : av[j][e] + pv[j][e];
+                else o[e] = gated ? pv[j][e] + g * av[j][e] + (1.f - g) * bv[j][e] : pv[j][e] + av[j][e] + bv[j][e];
             }
-            *(f4*)(t.F + m * D + c) = o;
+            if (m < args.M) *(f4*)(t.F + m * D + c) = o;
+            f2* fp = (f2*)(Fs + row * FS + c);        // rows are 8-byte aligned (FS even)
+            fp[0] = (f2){o[0], o[1]};
+            fp[1] = (f2){o[2], o[3]};
         }
-        f2* fp = (f2*)(Fs + row * FS + c);        // rows are 8-byte aligned (FS even)
-        fp[0] = (f2){o[0], o[1]};
-        fp[1] = (f2){o[2], o[3]};
     }
     __syncthreads();
 
@@ -190,15 +213,24 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
 
-    // ---- 1. dO tile -> LDS -----------------------------------------------------------------------------------------
-    for (int idx = tid; idx < R * d4; idx += NT) {
-        const int row = idx / d4, c = (idx - row * d4) * 4;
-        const int64_t m = m0 + row;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < args.M) v = *(const f4*)(t.dO + m * D + c);
-        f2* gp = (f2*)(Gs + row * FS + c);
-        gp[0] = (f2){v[0], v[1]};
-        gp[1] = (f2){v[2], v[3]};
+    // ---- 1. dO tile -> LDS (all loads of a thread in flight together) -----------------------------------------------------
+    constexpr int IT = R * d4 / NT, CH = IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : 1);
+    {
+        f4 v[IT];
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int idx = tid + j * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            const int64_t m = m0 + row;
+            v[j] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (m < args.M) v[j] = *(const f4*)(t.dO + m * D + c);
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int idx = tid + j * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            f2* gp = (f2*)(Gs + row * FS + c);
+            gp[0] = (f2){v[j][0], v[j][1]};
+            gp[1] = (f2){v[j][2], v[j][3]};
+        }
     }
     __syncthreads();
 
@@ -244,26 +276,35 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     // ---- 4. gate gradient, dprev (and the dim-align gradients) with full-row accesses ---------------------------------------
     float part = 0.f;
     const float ca = gated ? g : 1.f, cb = gated ? 1.f - g : 1.f;
-    for (int idx = tid; idx < R * d4; idx += NT) {
-        const int row = idx / d4, c = (idx - row * d4) * 4;
-        const int64_t m = m0 + row;
-        if (m >= args.M) continue;
-        const f2* gp = (const f2*)(Gs + row * FS + c);
-        const f2 lo = gp[0], hi = gp[1];
-        const f4 df = {lo[0], lo[1], hi[0], hi[1]};
-        if (gated) {
-            const f4 av = *(const f4*)(t.a + m * t.lda + c);
-            f4 ov = {0.f, 0.f, 0.f, 0.f};
-            if (t.type == 1) ov = *(const f4*)(t.b + m * t.ldb + c);
-            else if (t.prev) ov = *(const f4*)(t.prev + m * t.ldp + c);
+    for (int i0 = 0; i0 < IT; i0 += CH) {
+        f4 av[CH], ov[CH];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part += df[e] * (av[e] - ov[e]);
+        for (int j = 0; j < CH; ++j) {
+            const int idx = tid + (i0 + j) * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            const int64_t m = m0 + row;
+            av[j] = ov[j] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (gated && m < args.M) {
+                av[j] = *(const f4*)(t.a + m * t.lda + c);
+                if (t.type == 1) ov[j] = *(const f4*)(t.b + m * t.ldb + c);
+                else if (t.prev) ov[j] = *(const f4*)(t.prev + m * t.ldp + c);
+            }
         }
-        if (t.da) *(f4*)(t.da + m * D + c) = (f4){ca * df[0], ca * df[1], ca * df[2], ca * df[3]};
-        if (t.db) *(f4*)(t.db + m * D + c) = (f4){cb * df[0], cb * df[1], cb * df[2], cb * df[3]};
-        if (t.dprev) {
-            const float sc = (t.type == 0 && gated) ? cb : 1.f;
-            *(f4*)(t.dprev + m * D + c) = (f4){sc * df[0], sc * df[1], sc * df[2], sc * df[3]};
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = tid + (i0 + j) * NT, row = idx / d4, c = (idx - row * d4) * 4;
+            const int64_t m = m0 + row;
+            if (m >= args.M) continue;
+            const f2* gp = (const f2*)(Gs + row * FS + c);
+            const f2 lo = gp[0], hi = gp[1];
+            const f4 df = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part += df[e] * (av[j][e] - ov[j][e]);
+            if (t.da) *(f4*)(t.da + m * D + c) = (f4){ca * df[0], ca * df[1], ca * df[2], ca * df[3]};
+            if (t.db) *(f4*)(t.db + m * D + c) = (f4){cb * df[0], cb * df[1], cb * df[2], cb * df[3]};
+            if (t.dprev) {
+                const float sc = (t.type == 0 && gated) ? cb : 1.f;
+                *(f4*)(t.dprev + m * D + c) = (f4){sc * df[0], sc * df[1], sc * df[2], sc * df[3]};
+            }
         }
     }
     if (gated) {
