@@ -1,5 +1,6 @@
-// fp32 GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector
-// rate) for everything TRAINABLE on the hot path: SANB down/up projections, fc_* heads, com_dense, SASRec
+// fp32 GEMM for everything TRAINABLE on the hot path, on the 16-bit matrix cores with bf16x3 split operands (six MFMA
+// terms, fp32 accumulate: within 2^-23 of the products, see the K loop) or — G32_F32_CORES / iisan_set_gemm32_f32_cores —
+// on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector rate): SANB down/up projections, fc_* heads, com_dense, SASRec
 // projections/FFN and all their backward products (dX = dY·W, dW += dY^T·X).  These are <0.1 % of the step's
 // FLOPs but carry the parity budget, hence fp32 end to end.
 //
@@ -160,27 +161,61 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 __syncthreads();
                 fetch(u, k0 + (int64_t)DEPTH * TK);
                 const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
-                auto kstep = [&](int ks0) {
+                if (!(epi & G32_F32_CORES)) {
+                    // Split-operand path (default): every fp32 fragment element is cut into three bf16 pieces by truncation,
+                    // x = p0 + p1 + p2 EXACTLY (3 x 8 significant bits; fp32's range, so no scaling is needed), and the product
+                    // is the six leading terms  p0q0 + p0q1 + p1q0 + p1q1 + p0q2 + p2q0  on v_mfma_f32_16x16x32_bf16 with fp32
+                    // accumulation: what is dropped is below 2^-23 of a product — an fp32 FMA chain's class — at 6/16 of the f32
+                    // matrix cores' cycles (16x16x4 f32: 32 cycles for K = 4; 16x16x32 bf16: 16 cycles for K = 32).  The split
+                    // is done on the fragment registers after the LDS read, so staging, transposed operand layouts, split-K and
+                    // the epilogues are those of the fp32 path; tail K-tiles are zero-filled in LDS and run whole.
+                    typedef unsigned int u32;
 #pragma unroll
-                    for (int q = 0; q < KA; ++q) {
-                        const int ks = ks0 + q;               // rows beyond the tail are zero-filled: harmless
-                        float a[FM], b[FN];
+                    for (int ks2 = 0; ks2 < TK / 32; ++ks2) {
+                        b8 pa[FM][3], pb[FN][3];
+                        auto split8 = [&](const float* src, b8 (&dst)[3]) {
+                            float x[8];
 #pragma unroll
-                        for (int f = 0; f < FM; ++f) a[f] = As[wm * 16 * FM + f * 16 + fi][ks * 4 + fk];
+                            for (int h = 0; h < 4; ++h) {            // rows are 8-byte aligned (LD = 66 floats)
+                                const f2v t = *(const f2v*)(src + 2 * h);
+                                x[2 * h] = t[0]; x[2 * h + 1] = t[1];
+                            }
+                            u32 w[3][4];
 #pragma unroll
-                        for (int f = 0; f < FN; ++f) b[f] = Bs[wn * 16 * FN + f * 16 + fi][ks * 4 + fk];
+                            for (int h = 0; h < 4; ++h) {
+                                float r0 = x[2 * h], r1 = x[2 * h + 1];
 #pragma unroll
-                        for (int mf = 0; mf < FM; ++mf)
+                                for (int t3 = 0; t3 < 3; ++t3) {
+                                    const u32 u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+                                    w[t3][h] = (u1 & 0xffff0000u) | (u0 >> 16);        // two truncated bf16 pieces
+                                    if (t3 < 2) {
+                                        r0 -= __uint_as_float(u0 & 0xffff0000u);          // exact: the piece is the leading bits of r
+                                        r1 -= __uint_as_float(u1 & 0xffff0000u);
+                                    }
+                                }
+                            }
 #pragma unroll
-                            for (int nf = 0; nf < FN; ++nf)
-                                acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
+                            for (int t3 = 0; t3 < 3; ++t3) {
+                                const u4 v = {w[t3][0], w[t3][1], w[t3][2], w[t3][3]};
+                                dst[t3] = __builtin_bit_cast(b8, v);
+                            }
+                        };
+#pragma unroll
+                        for (int f = 0; f < FM; ++f) split8(&As[wm * 16 * FM + f * 16 + fi][ks2 * 32 + 8 * fk], pa[f]);
+#pragma unroll
+                        for (int f = 0; f < FN; ++f) split8(&Bs[wn * 16 * FN + f * 16 + fi][ks2 * 32 + 8 * fk], pb[f]);
+                        constexpr int TA_[6] = {0, 0, 1, 1, 0, 2}, TB_[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+                        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                            for (int mf = 0; mf < FM; ++mf)
+#pragma unroll
+                                for (int nf = 0; nf < FN; ++nf)
+                                    acc[t6 % KA][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[mf][TA_[t6]], pb[nf][TB_[t6]],
+                                                                                                  acc[t6 % KA][mf][nf], 0, 0, 0);
                     }
-                };
-                if (ksteps == TK / 4) {        // full tile: unrolled, so the LDS reads of later slices overlap the MFMAs of earlier ones
-#pragma unroll
-                    for (int ks0 = 0; ks0 < TK / 4; ks0 += KA) kstep(ks0);
-                } else {
-                    for (int ks0 = 0; ks0 < ksteps; ks0 += KA) kstep(ks0);
+                    __syncthreads();
+                    continue;
                 }
                 __syncthreads();
             }
@@ -290,6 +325,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
     if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
+// 0 (default): bf16x3 split-operand products on the 16-bit matrix cores; 1: exact fp32 FMA chains on the f32-input cores
+static int g_f32_cores = 0;
+extern "C" void iisan_set_gemm32_f32_cores(int32_t on) { g_f32_cores = on; }
+
 template <int FLAGS>
 int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, hipStream_t s) {
     if (fast) {
@@ -346,7 +385,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
                (q.lda & 3) == 0 && (q.ldb & 3) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.B & 15) == 0;
     }
     const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
-    const int epi = flags & ~structural;
+    const int epi = (flags & ~structural) | (g_f32_cores ? G32_F32_CORES : 0);
     switch (structural) {
 #define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, fast, s)
         G32_CASE(0);
