@@ -270,7 +270,6 @@ enum {
     G32_MUL_RELU_MASK = 32,  // C = (.) * (act_src > 0)
     G32_MUL_GELU_GRAD = 64,  // C = (.) * gelu'(act_src)
     G32_PREACT = 128,
-    G32_F32_CORES = 512,     // run on the f32-input matrix cores (exact fp32 FMA chain) instead of the bf16x3 split-operand path
     G32_DROPOUT = 256, // scale by the dropout keep factor before the residual add  // also store the pre-activation into act_src (as float* out) -- fwd of GELU adapters
 };
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s);

@@ -1,6 +1,5 @@
-// fp32 GEMM for everything TRAINABLE on the hot path, on the 16-bit matrix cores with bf16x3 split operands (six MFMA
-// terms, fp32 accumulate: within 2^-23 of the products, see the K loop) or — G32_F32_CORES / iisan_set_gemm32_f32_cores —
-// on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector rate): SANB down/up projections, fc_* heads, com_dense, SASRec
+// fp32 GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector
+// rate) for everything TRAINABLE on the hot path: SANB down/up projections, fc_* heads, com_dense, SASRec
 // projections/FFN and all their backward products (dX = dY·W, dW += dY^T·X).  These are <0.1 % of the step's
 // FLOPs but carry the parity budget, hence fp32 end to end.
 //
@@ -13,11 +12,24 @@
 // exposed HBM latencies for K = 768 — 80 us for a 1.1-GFLOP product, rocprofv3); up to 4 independent problems per launch
 // (blockIdx.z) so the cv / text / mm towers of the side network go out together; split-K (blockIdx.y) with fp32
 // atomics for the weight-gradient products whose M,N are tiny and K = number of item slots.
+//
+// Tried and dropped (round 2, MI355X): the same K loop on the 16-bit matrix cores with bf16x3 split operands (each fp32
+// fragment element cut into three bf16 pieces by truncation after the LDS read, six MFMA terms, fp32 accumulate — 6/16 of
+// the matrix cycles, all 175 GPU tests green at unchanged tolerances) ran the Cached step in 7.37 ms against 7.44 and the
+// Versa step in 10.7 ms against 9.8: this kernel is bound by its staging (global -> registers -> LDS -> fragments, two
+// barriers per K-tile), not by the matrix pipe, and the split added VALU work to it.
 #include "common.h"
 
 namespace {
 
 constexpr int TN = 64, TK = 64, LD = 66;
+// Operands whose memory layout is K-major (G32_TA / G32_TB: contraction index along the rows) are staged K-MAJOR in LDS
+// too: a thread's 16-byte load (4 consecutive rows at one k) becomes ONE ds_write_b128 and the MFMA fragment read walks a
+// row of the image (16 consecutive floats per quarter-wave: conflict-free with the k-row stride = 16 mod 32 banks).  The
+// first version transposed while storing — 16 scalar LDS writes per operand and thread and K-tile, 4- to 8-way bank
+// conflicts — which cost the weight-gradient products (both operands K-major) about as much as their MFMAs.
+__host__ __device__ constexpr int ldt(int rows) { return rows == 16 ? 48 : rows + 16; }
+__host__ __device__ constexpr int smem_floats(int rows) { return rows * LD > TK * ldt(rows) ? rows * LD : TK * ldt(rows); }
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 struct Gemm32Batch {
@@ -61,17 +73,16 @@ __device__ __forceinline__ void load_tile(f4 (&v)[ROWS / 16], const float* __res
     }
 }
 template <int ROWS>
-__device__ __forceinline__ void store_tile(float (*S)[LD], const f4 (&v)[ROWS / 16], bool trans, int tid) {
+__device__ __forceinline__ void store_tile(float* S, const f4 (&v)[ROWS / 16], bool trans, int tid) {
     constexpr int TPR = ROWS / 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
         if (!trans) {
-            float* d = &S[(tid >> 4) + 16 * i][(tid & 15) * 4];         // 8-byte aligned (row stride 264 B)
+            float* d = S + ((tid >> 4) + 16 * i) * LD + (tid & 15) * 4;         // 8-byte aligned (row stride 264 B)
             *(f2v*)d = (f2v){v[i][0], v[i][1]};
             *(f2v*)(d + 2) = (f2v){v[i][2], v[i][3]};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S[(tid % TPR) * 4 + e][tid / TPR + (256 / TPR) * i] = v[i][e];
+        } else {                                                                 // K-major image: row k, 4 consecutive operand rows
+            *(f4*)(S + (tid / TPR + (256 / TPR) * i) * ldt(ROWS) + (tid % TPR) * 4) = v[i];
         }
     }
 }
@@ -89,8 +100,9 @@ template <int FLAGS, int TMV, bool FAST>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
     constexpr int TM = TMV;
     constexpr int WM = TMV >= 32 ? 2 : 1, WN = 4 / WM, FM = TMV / 16 / WM, FN = 4 / WN;
-    __shared__ __attribute__((aligned(16))) float As[TM][LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TN][LD];
+    __shared__ __attribute__((aligned(16))) float As_[smem_floats(TM)];
+    __shared__ __attribute__((aligned(16))) float Bs_[smem_floats(TN)];
+    float (*As)[LD] = (float (*)[LD])As_;           // row-major view: operand staging (not transposed) and the epilogue tile
     const Gemm32Prob& p = batch.p[blockIdx.z];
     const int tiles_n = (p.N + TN - 1) / TN;
     const int64_t tiles_m = (p.M + TM - 1) / TM;
@@ -156,67 +168,11 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
         for (int u = 0; u < DEPTH; ++u) {
             const int64_t k0 = kb + (int64_t)u * TK;
             if (k0 < kend) {                          // wave-uniform
-                store_tile<TM>(As, ra[u], TA, tid);
-                store_tile<TN>(Bs, rb[u], TB, tid);
+                store_tile<TM>(As_, ra[u], TA, tid);
+                store_tile<TN>(Bs_, rb[u], TB, tid);
                 __syncthreads();
                 fetch(u, k0 + (int64_t)DEPTH * TK);
                 const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
-                if (!(epi & G32_F32_CORES)) {
-                    // Split-operand path (default): every fp32 fragment element is cut into three bf16 pieces by truncation,
-                    // x = p0 + p1 + p2 EXACTLY (3 x 8 significant bits; fp32's range, so no scaling is needed), and the product
-                    // is the six leading terms  p0q0 + p0q1 + p1q0 + p1q1 + p0q2 + p2q0  on v_mfma_f32_16x16x32_bf16 with fp32
-                    // accumulation: what is dropped is below 2^-23 of a product — an fp32 FMA chain's class — at 6/16 of the f32
-                    // matrix cores' cycles (16x16x4 f32: 32 cycles for K = 4; 16x16x32 bf16: 16 cycles for K = 32).  The split
-                    // is done on the fragment registers after the LDS read, so staging, transposed operand layouts, split-K and
-                    // the epilogues are those of the fp32 path; tail K-tiles are zero-filled in LDS and run whole.
-                    typedef unsigned int u32;
-#pragma unroll
-                    for (int ks2 = 0; ks2 < TK / 32; ++ks2) {
-                        b8 pa[FM][3], pb[FN][3];
-                        auto split8 = [&](const float* src, b8 (&dst)[3]) {
-                            float x[8];
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {            // rows are 8-byte aligned (LD = 66 floats)
-                                const f2v t = *(const f2v*)(src + 2 * h);
-                                x[2 * h] = t[0]; x[2 * h + 1] = t[1];
-                            }
-                            u32 w[3][4];
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                float r0 = x[2 * h], r1 = x[2 * h + 1];
-#pragma unroll
-                                for (int t3 = 0; t3 < 3; ++t3) {
-                                    const u32 u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
-                                    w[t3][h] = (u1 & 0xffff0000u) | (u0 >> 16);        // two truncated bf16 pieces
-                                    if (t3 < 2) {
-                                        r0 -= __uint_as_float(u0 & 0xffff0000u);          // exact: the piece is the leading bits of r
-                                        r1 -= __uint_as_float(u1 & 0xffff0000u);
-                                    }
-                                }
-                            }
-#pragma unroll
-                            for (int t3 = 0; t3 < 3; ++t3) {
-                                const u4 v = {w[t3][0], w[t3][1], w[t3][2], w[t3][3]};
-                                dst[t3] = __builtin_bit_cast(b8, v);
-                            }
-                        };
-#pragma unroll
-                        for (int f = 0; f < FM; ++f) split8(&As[wm * 16 * FM + f * 16 + fi][ks2 * 32 + 8 * fk], pa[f]);
-#pragma unroll
-                        for (int f = 0; f < FN; ++f) split8(&Bs[wn * 16 * FN + f * 16 + fi][ks2 * 32 + 8 * fk], pb[f]);
-                        constexpr int TA_[6] = {0, 0, 1, 1, 0, 2}, TB_[6] = {0, 1, 0, 1, 2, 0};
-#pragma unroll
-                        for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-                            for (int mf = 0; mf < FM; ++mf)
-#pragma unroll
-                                for (int nf = 0; nf < FN; ++nf)
-                                    acc[t6 % KA][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[mf][TA_[t6]], pb[nf][TB_[t6]],
-                                                                                                  acc[t6 % KA][mf][nf], 0, 0, 0);
-                    }
-                    __syncthreads();
-                    continue;
-                }
                 __syncthreads();
             }
         }
@@ -325,9 +281,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
     if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
-// 0 (default): bf16x3 split-operand products on the 16-bit matrix cores; 1: exact fp32 FMA chains on the f32-input cores
-static int g_f32_cores = 0;
-extern "C" void iisan_set_gemm32_f32_cores(int32_t on) { g_f32_cores = on; }
+// launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
+// before split-K stops adding slices
+static int g_tm_thresh = 192, g_splitk_target = 1024;
+extern "C" void iisan_set_gemm32_tuning(int32_t tm_thresh, int32_t splitk_target) {
+    g_tm_thresh = tm_thresh > 0 ? tm_thresh : 192;
+    g_splitk_target = splitk_target > 0 ? splitk_target : 1024;
+}
 
 template <int FLAGS>
 int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, hipStream_t s) {
@@ -365,13 +325,13 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     // K instead and keep 64)
     int TM = 64;
     if (!(flags & G32_ACCUM)) {
-        if (tiles_for(64) * nprob < 192) TM = tiles_for(32) * nprob >= 192 ? 32 : 16;
+        if (tiles_for(64) * nprob < g_tm_thresh) TM = tiles_for(32) * nprob >= g_tm_thresh ? 32 : 16;
     }
     const int64_t max_tiles = tiles_for(TM);
     IISAN_CHECK_SHAPE(max_tiles < (1ll << 31), "gemm32: grid too large");
     int splitk = 1;
     if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
-        const int64_t want = ceil_div(1024, max_tiles * nprob);
+        const int64_t want = ceil_div(g_splitk_target, max_tiles * nprob);
         const int64_t maxs = ceil_div(min_k, 2 * TK);
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (splitk < 1) splitk = 1;
@@ -385,7 +345,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
                (q.lda & 3) == 0 && (q.ldb & 3) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.B & 15) == 0;
     }
     const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
-    const int epi = (flags & ~structural) | (g_f32_cores ? G32_F32_CORES : 0);
+    const int epi = flags & ~structural;
     switch (structural) {
 #define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, fast, s)
         G32_CASE(0);
