@@ -173,6 +173,30 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 __syncthreads();
                 fetch(u, k0 + (int64_t)DEPTH * TK);
                 const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
+                auto kstep = [&](int ks0) {
+#pragma unroll
+                    for (int q = 0; q < KA; ++q) {
+                        const int ks = ks0 + q;               // rows beyond the tail are zero-filled: harmless
+                        float a[FM], b[FN];
+#pragma unroll
+                        for (int f = 0; f < FM; ++f)
+                            a[f] = TA ? As_[(ks * 4 + fk) * ldt(TM) + wm * 16 * FM + f * 16 + fi] : As_[(wm * 16 * FM + f * 16 + fi) * LD + ks * 4 + fk];
+#pragma unroll
+                        for (int f = 0; f < FN; ++f)
+                            b[f] = TB ? Bs_[(ks * 4 + fk) * ldt(TN) + wn * 16 * FN + f * 16 + fi] : Bs_[(wn * 16 * FN + f * 16 + fi) * LD + ks * 4 + fk];
+#pragma unroll
+                        for (int mf = 0; mf < FM; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < FN; ++nf)
+                                acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
+                    }
+                };
+                if (ksteps == TK / 4) {        // full tile: unrolled, so the LDS reads of later slices overlap the MFMAs of earlier ones
+#pragma unroll
+                    for (int ks0 = 0; ks0 < TK / 4; ks0 += KA) kstep(ks0);
+                } else {
+                    for (int ks0 = 0; ks0 < ksteps; ks0 += KA) kstep(ks0);
+                }
                 __syncthreads();
             }
         }
@@ -283,9 +307,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
 
 // launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
 // before split-K stops adding slices
-static int g_tm_thresh = 192, g_splitk_target = 1024;
+static int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
 extern "C" void iisan_set_gemm32_tuning(int32_t tm_thresh, int32_t splitk_target) {
-    g_tm_thresh = tm_thresh > 0 ? tm_thresh : 192;
+    g_tm_thresh = tm_thresh > 0 ? tm_thresh : 512;
     g_splitk_target = splitk_target > 0 ? splitk_target : 1024;
 }
 
