@@ -89,6 +89,7 @@ EXTRA_SIGNATURES = {
     "iisan_set_attn_debug": (None, [i32]),
     "iisan_set_x3": (None, [i32]),
     "iisan_set_sanb_fused": (None, [i32]),
+    "iisan_set_ce_fast": (None, [i32]),
     "iisan_set_gemm32_tuning": (None, [i32, i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),
