@@ -228,7 +228,8 @@ struct Gemm16Args {
     int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
     // EPI_F32 (split-operand GEMM of the trainable path, split.hip): out fp32 = acc * inv_a[0] * inv_b[0] (+ bias) (+ resid)
     const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
-    int32_t atomic;     // 1: accumulate into out with fp32 atomics (split-K partial sums, weight-gradient +=)
+    int32_t atomic;     // 1: accumulate into out with fp32 atomics (bench knob only: ~20 G atomics/s chip-wide, far too slow)
+    int64_t split_stride;   // EPI_F32 split-K: K-split y writes its partial product to out + y*split_stride (bias / resid: reducer)
 };
 enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5 };
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)

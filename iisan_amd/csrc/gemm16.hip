@@ -134,14 +134,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                 const float ia = p.inv_a ? p.inv_a[0] : 1.f, ib = p.inv_b ? p.inv_b[0] : 1.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = v[r] * ia * ib;
-                float* op = (float*)p.out + m * p.ldo + n;
-                const bool first = blockIdx.y == 0;    // bias / residual are added by one K-split only
-                if (p.bias && first) {
+                float* op = (float*)p.out + (int64_t)blockIdx.y * p.split_stride + m * p.ldo + n;
+                const bool first = gridDim.y == 1 || p.atomic;    // split-K partial products: bias / residual are the reducer's
+                if (p.bias && first && (blockIdx.y == 0)) {
                     const f4 b0 = *(const f4*)(p.bias + n), b1 = *(const f4*)(p.bias + n + 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
                 }
-                if (p.resid && first) {
+                if (p.resid && first && (blockIdx.y == 0)) {
                     const float* rp = p.resid + m * p.ldo + n;
                     const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
 #pragma unroll
@@ -219,12 +219,21 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 // that measures the frozen encoders' GEMMs only.
 int launch_gemm16_f32(const Gemm16Args& a, int ksplit, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0 && a.N % 8 == 0 && a.ldo % 4 == 0, "gemm16_f32: bad shape");
-    IISAN_CHECK_SHAPE(ksplit >= 1 && (ksplit == 1 || a.atomic), "gemm16_f32: split-K needs atomic accumulation");
+    IISAN_CHECK_SHAPE(ksplit >= 1 && (ksplit == 1 || a.atomic || a.split_stride > 0), "gemm16_f32: split-K needs a partial-product buffer");
     const int64_t tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
     IISAN_CHECK_SHAPE(tiles < (1ll << 31), "gemm16_f32: grid too large");
     hipLaunchKernelGGL((gemm16_kernel<F16, EPI_F32>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, s, a);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
+}
+
+// bench / test entry: fp16 operands [M,K] x [N,K]^T -> fp32 out (plain or split-K with atomics into a caller-zeroed out)
+extern "C" int iisan_gemm16_f32(const void* A, const void* W, float* out, int64_t M, int32_t N, int32_t K, int32_t ksplit,
+                                void* stream) {
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N;
+    a.atomic = ksplit > 1 ? 1 : 0;
+    return launch_gemm16_f32(a, ksplit, (hipStream_t)stream);
 }
 
 bool gemm16_p256_applicable(const Gemm16Args& a);

@@ -351,11 +351,11 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 extern "C" void iisan_set_sanb_fused(int32_t on) { g_use_sanb = on; }
 
 void gemm_x3_set_min_flops(double f);
-// 0 = off, 1 = default (products of at least 150 GFLOP), 2 = every product whose shape allows it (tests: the small golden
+// 0 = off, 1 = default (products of at least 8 GFLOP), 2 = every product whose shape allows it (tests: the small golden
 // fixtures then run through the split-operand path too)
 extern "C" void iisan_set_x3(int32_t mode) {
     g_use_x3 = mode != 0;
-    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 1.5e11);
+    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 8e9);
 }
 
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {

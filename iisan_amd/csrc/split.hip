@@ -28,7 +28,10 @@ struct SplitArgs {
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
                                                    uint32_t* amax_bits) {
-    // cols % 4 == 0 and 16-byte aligned rows are checked on the host
+    // cols % 4 == 0 and 16-byte aligned rows are checked on the host.  ONE atomic per workgroup and at most 512
+    // workgroups: same-address atomics serialise (the first version issued one per wave from 2048 workgroups — 8192
+    // atomics on one word — and took 103 us for a 35 MB tensor, 10x its HBM time).
+    __shared__ float red[4];
     const int64_t c4 = cols / 4, total = rows * c4;
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -37,7 +40,12 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bits
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bit patterns
+    }
 }
 
 // s = 2^(13 - floor(log2 amax)): the largest element lands in [2^13, 2^14) (fp16 max 65504); amax == 0 or denormal -> s = 1
@@ -127,6 +135,22 @@ __global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
     }
 }
 
+// C[m][n] = sum_y P[y][m][n] (+ bias[n]) (+ resid[m][n]); 16-byte lanes, fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, int ks, int64_t stride, const float* __restrict__ bias,
+                                                            const float* resid, float* C, int64_t M, int N, int ldc) {
+    const int n4 = N / 4;
+    const int64_t total = M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        f4 v = *(const f4*)(P + m * N + n);
+        for (int y = 1; y < ks; ++y) v += *(const f4*)(P + y * stride + m * N + n);
+        if (bias) v += *(const f4*)(bias + n);
+        if (resid) v += *(const f4*)(resid + m * ldc + n);
+        *(f4*)(C + m * ldc + n) = v;
+    }
+}
+
 int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
                   int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, hipStream_t s) {
     SplitArgs a{};
@@ -136,7 +160,7 @@ int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_
     a.cols = trans ? op_rows : K;
     IISAN_CHECK_SHAPE(a.cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "split: source rows must be 16-byte aligned");
     int64_t blocks = ceil_div(a.rows * (a.cols / 4), 256 * 4);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, a.rows, a.cols, ld, amax_bits);
     IISAN_LAUNCH_OK();
@@ -155,9 +179,21 @@ int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_
 
 int launch_gemm16_f32(const Gemm16Args& a, int ksplit, hipStream_t s);      // gemm16.hip
 
+// K-splits of a product: as many as it takes to put ~1.5 workgroups on every CU, at least 16 K-steps each, at most 8.
+// Partial products go to the workspace and a small reducer adds them (fp32 atomics run at ~20 G/s chip-wide: a split-K
+// epilogue on them took 430 us for 8 M outputs, tools/g16f32_time.py).
+static int x3_ksplit(int64_t mp, int64_t np, int64_t kp) {
+    const int64_t tiles = (mp / 128) * (np / 128), nk = 3 * kp / 64;
+    int ks = 1;
+    while (tiles * ks < 384 && ks < 8 && nk / (ks * 2) >= 16) ks *= 2;
+    return ks;
+}
+
 size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t kp = ceil_div(K, 64) * 64, mp = ceil_div(M, 128) * 128, np = ceil_div(N, 128) * 128;
-    return align_up((size_t)mp * 3 * kp * 2, 256) + align_up((size_t)np * 3 * kp * 2, 256) + 256;
+    const int ks = x3_ksplit(mp, np, kp);
+    return align_up((size_t)mp * 3 * kp * 2, 256) + align_up((size_t)np * 3 * kp * 2, 256) + 256 +
+           (ks > 1 ? align_up((size_t)ks * M * N * 4, 256) : 0);
 }
 
 // Worth the four extra small launches (amax + split per operand)?  Only the big products.
@@ -169,19 +205,19 @@ static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
     if (p.resid && (p.ldr != p.ldc)) return false;
     return true;
 }
-// Below this many FLOPs the extra passes (amax + split per operand, split-K atomics) cost more than the matrix rate
-// gains.  Measured (tools/x3_time.py, MI355X): gemm32 reaches 75-118 TF on these shapes; this front end with the 128x128
-// GEMM kernel only wins from ~1.5e11 FLOP ([11264, 8192] x [8192, 1024]: 1.33x) — every product of the benched
-// configurations stays on the f32 matrix cores until the operand images are produced by the upstream kernels.
-static double g_x3_min_flops = 1.5e11;
+// Below this many FLOPs the extra passes (memset, amax + split per operand, ~7 dependent launches) cost more than the
+// matrix rate gains.  Measured (tools/x3_time.py, MI355X; gemm32 reaches 83-98 TF on these shapes):
+//   [11264,768]x[768,768] fwd / dX 106 us vs 151-160 (1.4-1.5x), its dW 135 vs 160 (1.2x), Versa dim-align [1408,8192]->1024
+//   172 vs 265 (1.5x) and its dW 133 vs 241 (1.8x); [1408,768]x[768,768] 43 vs 30 us (0.7x: stays on the f32 cores).
+static double g_x3_min_flops = 8e9;
 void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f; }
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
     return x3_shape_ok(p, flags) && 2.0 * (double)p.M * (double)p.N * (double)p.K >= g_x3_min_flops;
 }
 
 // C[M,N] (=|+=) op(A)[M,K] · op(B)[K,N] + bias (+ resid), same operand conventions as launch_gemm32
-// (A stored [M,K] or, G32_TA, [K,M]; B stored [N,K] or, G32_TB, [K,N]); G32_ACCUM: C += via fp32 atomics (C pre-zeroed
-// or holding the running sum).  `ws` >= gemm_x3_ws_bytes(M, N, K).
+// (A stored [M,K] or, G32_TA, [K,M]; B stored [N,K] or, G32_TB, [K,N]); G32_ACCUM: C += (read-modify-write, no atomics).
+// `ws` >= gemm_x3_ws_bytes(M, N, K).
 static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
     return launch_gemm_x3_any(p, flags, ws, ws_bytes, s);
@@ -204,19 +240,23 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t w
     Gemm16Args g{};
     g.A = A16; g.W = B16; g.bias = p.bias; g.out = p.C; g.resid = p.resid;
     g.M = p.M; g.N = p.N; g.K = (int32_t)(3 * kp); g.lda = g.ldw = (int32_t)(3 * kp); g.ldo = p.ldc;
-    g.inv_a = inv; g.inv_b = inv + 1; g.atomic = (flags & G32_ACCUM) ? 1 : 0;
-    // split K until the launch has ~2 workgroups per CU (the kernel runs two 128x128 tiles per CU)
-    const int64_t tiles = (mp / 128) * (np / 128);
-    int64_t ks = 1;
-    const int64_t nk = 3 * kp / 64;
-    while (tiles * ks < 384 && ks * 2 <= nk / 8 && ks < 64) ks *= 2;
-    if (p.resid && p.resid == p.C) ks = 1;        // in-place residual: C cannot be zeroed for partial sums
-    if (ks > 1 && !g.atomic) {
-        // partial sums meet in C through atomics: start from bias (+ resid) written by ... a zeroed C
-        IISAN_HIP_OK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, (size_t)p.M, s));
-        g.atomic = 1;
+    g.inv_a = inv; g.inv_b = inv + 1; g.atomic = 0;
+    const bool accum = (flags & G32_ACCUM) != 0;
+    const int ks = x3_ksplit(mp, np, kp);
+    if (ks == 1) {
+        // "+=": the previous value of C is the residual (read-modify-write by the one lane that owns the element)
+        if (accum) { IISAN_CHECK_SHAPE(!p.resid, "gemm_x3: accumulate and residual together"); g.resid = p.C; }
+        return launch_gemm16_f32(g, 1, s);
     }
-    return launch_gemm16_f32(g, (int)ks, s);
+    float* P = (float*)(w + 256);
+    g.out = P; g.ldo = p.N; g.bias = nullptr; g.resid = nullptr; g.split_stride = p.M * (int64_t)p.N;
+    IISAN_TRY(launch_gemm16_f32(g, ks, s));
+    int64_t blocks = ceil_div(p.M * (p.N / 4), 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P, ks, g.split_stride, p.bias,
+                       accum ? p.C : p.resid, p.C, p.M, p.N, p.ldc);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
 }
 
 extern "C" size_t iisan_gemm_x3_ws_bytes(int64_t M, int32_t N, int64_t K) { return gemm_x3_ws_bytes(M, N, K); }

@@ -81,7 +81,7 @@ def sanb_mode(lib, request):
 @pytest.fixture
 def x3_mode(lib, request):
     """Route of the side network's large Linear layers (`csrc/sidenet.hip:gemm_group`): 1 = product default (split-operand
-    fp16 MFMA GEMM only for products of >= 150 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
+    fp16 MFMA GEMM for products of >= 8 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
     shape allows it — so the small reference goldens pin that path too — 0 = f32 matrix cores only."""
     lib.iisan_set_x3(request.param)
     yield request.param
