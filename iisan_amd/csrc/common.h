@@ -260,7 +260,12 @@ struct Gemm32Prob {
     int64_t M; int32_t N; int64_t K;
     int32_t lda, ldb, ldc, ldr;
     DropCfg drop;          // G32_DROPOUT: C = dropout(acc + bias [act]) (+ resid); element index = m*ldc + n
+    int64_t ksplit_stride; // internal (split-K through a scratch buffer): K-split y writes its raw partial product at C + y*ksplit_stride
 };
+// Scratch for split-K of skinny long-K products that are NOT "+=" (their epilogue — bias, activation, masks — has to see the
+// complete sum, so the partial products meet in a buffer and a reducer applies it).  Registered by an executor for the
+// duration of its call (stream-ordered use; one host thread per process issues the work); null = never split.
+void gemm32_set_scratch(float* ws, size_t floats);
 // flags for launch_gemm32
 enum {
     G32_TA = 1,        // A stored [K, M]

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     }
 
     const bool first_split = blockIdx.y == 0;
+    float* const Cp = p.C + (int64_t)blockIdx.y * p.ksplit_stride;     // ksplit_stride != 0: raw partial product of this K-split
     // Epilogue.  In the MFMA layout a lane owns 4 rows x 1 column of a fragment: stores (and the residual / activation
     // reads) straight from it are 4-byte accesses, 256 B per wave instruction — the [M,64]·[64,768] products of the side
     // network (3 x 35 MB out, 35 MB residual in) ran at 1 TB/s, 5x their HBM time (rocprofv3, Cached step).  So the tile
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 v[e] = x;
             }
             if (p.resid && first_split) v += *(const f4*)(p.resid + m * p.ldr + n);
-            *(f4*)(p.C + ci) = v;
+            *(f4*)(Cp + ci) = v;
         }
         return;
     }
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 if constexpr (ACC)
                     atomicAdd(p.C + m * p.ldc + n, v);
                 else
-                    p.C[m * p.ldc + n] = v;
+                    Cp[m * p.ldc + n] = v;
             }
         }
 }
@@ -305,6 +306,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
     if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
+// C = epilogue(sum_y P[y] + bias) (+ resid): the split-K partial products of up to 4 problems, fixed summation order
+struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; };
+__global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int ks, int epi) {
+    const Gemm32Prob& p = rb.p[blockIdx.z];
+    const float* P = rb.P[blockIdx.z];
+    const int64_t stride = rb.stride[blockIdx.z], total = p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / p.N;
+        const int n = (int)(i - m * p.N);
+        float v = P[i];
+        for (int y = 1; y < ks; ++y) v += P[y * stride + i];
+        if (p.bias) v += p.bias[n];
+        const int64_t ci = m * p.ldc + n;
+        if (epi & G32_PREACT) ((float*)p.act_src)[ci] = v;
+        if (epi & G32_RELU) v = fmaxf(v, 0.f);
+        if (epi & G32_GELU) v = gelu_erf(v);
+        if (epi & G32_MUL_RELU_MASK) v = p.act_src[ci] > 0.f ? v : 0.f;
+        if (epi & G32_MUL_GELU_GRAD) v *= gelu_erf_grad(p.act_src[ci]);
+        if (epi & G32_DROPOUT) v *= drop_scale(p.drop.seed, p.drop.site, (uint64_t)ci, p.drop.thr24, p.drop.inv_keep);
+        if (p.resid) v += p.resid[m * p.ldr + n];
+        p.C[ci] = v;
+    }
+}
+
+float* g_scratch = nullptr;
+size_t g_scratch_floats = 0;
+
 // launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
 // before split-K stops adding slices
 static int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
@@ -327,6 +355,8 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, hi
 }
 
 }  // namespace
+
+void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
 
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
     IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
@@ -360,6 +390,30 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (splitk < 1) splitk = 1;
     }
+    // Skinny long-K products that are not "+=" (the [M, 8192] -> 64 projections of Versa's text tower: 88 workgroups, each a
+    // serial chain of 128 K-tiles — 77 us for 1.5 GFLOP): spread K over the chip through the executor's scratch buffer and
+    // let a reducer apply the epilogue to the complete sums.
+    Gemm32Batch orig = b;
+    bool via_scratch = false;
+    if (!(flags & G32_ACCUM) && g_scratch && max_tiles * nprob <= 192) {
+        int64_t max_k = 0, need = 0;
+        for (int i = 0; i < nprob; ++i) if (probs[i].K > max_k) max_k = probs[i].K;
+        int ks = (int)(max_k / (8 * TK));
+        if (ks > 8) ks = 8;
+        for (int i = 0; i < nprob; ++i) need += (int64_t)ks * (int64_t)align_up((size_t)(probs[i].M * probs[i].N), 64);
+        if (ks >= 2 && (size_t)need <= g_scratch_floats) {
+            int64_t off = 0;
+            for (int i = 0; i < nprob; ++i) {
+                Gemm32Prob& q = b.p[i];
+                q.C = g_scratch + off; q.ldc = q.N; q.bias = nullptr; q.resid = nullptr; q.act_src = nullptr;
+                q.ksplit_stride = (int64_t)align_up((size_t)(q.M * q.N), 64);
+                off += ks * q.ksplit_stride;
+            }
+            IISAN_HIP_OK(hipMemsetAsync(g_scratch, 0, (size_t)need * sizeof(float), s));     // a K-split beyond a short problem's K writes nothing
+            splitk = ks;
+            via_scratch = true;
+        }
+    }
     dim3 grid((unsigned)max_tiles, (unsigned)splitk, (unsigned)nprob);
     // FAST fetch: full tiles, whole K-tiles per split, 16-byte aligned operand rows — for every problem of the launch
     bool fast = true;
@@ -369,9 +423,10 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
                (q.lda & 3) == 0 && (q.ldb & 3) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.B & 15) == 0;
     }
     const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
-    const int epi = flags & ~structural;
+    const int epi = via_scratch ? 0 : (flags & ~structural);
+    int rc;
     switch (structural) {
-#define G32_CASE(F) case (F): return launch_flags<(F)>(b, grid, TM, epi, fast, s)
+#define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, s); break
         G32_CASE(0);
         G32_CASE(G32_TA);
         G32_CASE(G32_TB);
@@ -383,6 +438,20 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
 #undef G32_CASE
         default: iisan_set_error("gemm32: bad flags 0x%x", flags); return IISAN_EBADSHAPE;
     }
+    if (rc != IISAN_OK || !via_scratch) return rc;
+    ReduceBatch rb{};
+    int64_t max_mn = 0;
+    for (int i = 0; i < nprob; ++i) {
+        rb.p[i] = orig.p[i];
+        rb.P[i] = b.p[i].C;
+        rb.stride[i] = b.p[i].ksplit_stride;
+        if (orig.p[i].M * orig.p[i].N > max_mn) max_mn = orig.p[i].M * orig.p[i].N;
+    }
+    int64_t blocks = ceil_div(max_mn, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)blocks, 1, (unsigned)nprob), dim3(256), 0, s, rb, splitk, flags & ~structural);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
 }
 
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
