@@ -395,7 +395,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     // let a reducer apply the epilogue to the complete sums.
     Gemm32Batch orig = b;
     bool via_scratch = false;
-    if (!(flags & G32_ACCUM) && g_scratch && max_tiles * nprob <= 192) {
+    if (!(flags & G32_ACCUM) && g_scratch && max_tiles <= 192) {
         int64_t max_k = 0, need = 0;
         for (int i = 0; i < nprob; ++i) if (probs[i].K > max_k) max_k = probs[i].K;
         int ks = (int)(max_k / (8 * TK));
