@@ -47,6 +47,9 @@ def parse(argv=None):
     ap.add_argument("--chunk", type=int, default=0, help="items per encoder chunk (0 = whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (no `secondary` list)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the kernel-family check before the timed region (profiling runs: its extra forward passes would "
+                         "be counted among the traced launches)")
     ap.add_argument("--dedup", action="store_true",
                     help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
                          "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
@@ -426,7 +429,7 @@ def main():
         out = cached_line(a, lib, dev, rank, world, a.steps, a.warmup)
     else:
         unc = Uncached(a, lib, dev, rank, world)
-        check = unc.kernel_family_check() if (world == 1 and a.bs >= 64 and not a.dedup) else None
+        check = unc.kernel_family_check() if (world == 1 and a.bs >= 64 and not a.dedup and not a.no_check) else None
         out = unc.line(a.steps, a.warmup, a.dtype, a.full_blocks)
         if check:
             out["config"]["kernel_family_check"] = check
