@@ -230,6 +230,7 @@ struct Gemm16Args {
     const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
     int32_t atomic;     // 1: accumulate into out with fp32 atomics (bench knob only: ~20 G atomics/s chip-wide, far too slow)
     int64_t split_stride;   // EPI_F32 split-K: K-split y writes its partial product to out + y*split_stride (bias / resid: reducer)
+    const int32_t* skip_last_third;   // EPI_F32: device flag; when it reads 0 the last third of K is all zeros and is not multiplied
 };
 enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5 };
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
@@ -276,6 +277,7 @@ enum {
     G32_MUL_RELU_MASK = 32,  // C = (.) * (act_src > 0)
     G32_MUL_GELU_GRAD = 64,  // C = (.) * gelu'(act_src)
     G32_PREACT = 128,
+    G32_HINT_B_EXACT16 = 1024,   // gemm_x3 only: the B operand is probably exact in fp16 (cached taps): its lo plane goes last
     G32_DROPOUT = 256, // scale by the dropout keep factor before the residual add  // also store the pre-activation into act_src (as float* out) -- fwd of GELU adapters
 };
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s);

@@ -81,12 +81,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
 
     int nk = p.K / BK, k_first = 0;
     if constexpr (EPI == EPI_F32) {                   // split-K: blockIdx.y owns a contiguous range of K-tiles
-        const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+        // split-operand products: when one operand turned out exact in fp16 its lo plane (the last third of K) is zero;
+        // the K-splits share what is left
+        const int k_live = (p.skip_last_third && p.skip_last_third[0] == 0) ? nk / 3 * 2 : nk;
+        const int per = (k_live + (int)gridDim.y - 1) / (int)gridDim.y;
         k_first = (int)blockIdx.y * per;
-        nk = nk - k_first < per ? nk - k_first : per;
-        if (nk <= 0) return;
+        int k_end = k_first + per;
+        if (k_end > k_live) k_end = k_live;
+        nk = k_end - k_first;
+        if (nk < 0) nk = 0;                           // nothing to multiply: the epilogue still writes this split's zeros
     }
-    stage(k_first, 0);
+    if (nk > 0) stage(k_first, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {

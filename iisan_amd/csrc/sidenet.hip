@@ -266,7 +266,7 @@ int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStr
         if (b.x3 && gemm_x3_applicable(pr[i], flags)) IISAN_TRY(launch_gemm_x3(pr[i], flags, b.x3, b.x3_bytes, s));
         else rest[nr++] = pr[i];
     }
-    if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags, s));
+    if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags & ~G32_HINT_B_EXACT16, s));
     return IISAN_OK;
 }
 
@@ -569,7 +569,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
         if (need_dp) {                        // DP = tap_wide · Pd^T + bd
             const int zw = p.text_wide ? 1 : 0, i = sm.mm_i;
             Gemm32Prob pd = prob(b.dDP, p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
-            IISAN_TRY(gemm_group(&pd, 1, G32_TA | G32_TB | G32_ACCUM, b, s));     // dPd += dDP^T · tap
+            IISAN_TRY(gemm_group(&pd, 1, G32_TA | G32_TB | G32_ACCUM | G32_HINT_B_EXACT16, b, s));     // dPd += dDP^T · tap
             const float* X[1] = {b.dDP};
             float* O[1] = {G(p.dpw(i) + 1)};
             int64_t Ms[1] = {M};

@@ -24,6 +24,7 @@ struct SplitArgs {
     int32_t trans;         // 1: the operand is x^T (operand row = source column, K runs over source rows)
     uint32_t* amax_bits;   // in: bit pattern of max|x| (amax kernel)
     float* inv_scale;      // out: 1/s
+    int32_t* lo_flag;      // out: set to 1 when any lo element is non-zero (pre-zeroed; plain stores of the same value)
 };
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
     const float s = scale_of(*a.amax_bits);
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
     const int64_t g8 = a.kp / 8, total = a.out_rows * g8;
+    int any_lo = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / g8, k = (i - r * g8) * 8;
         h8 hi, lo;
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
         *(h8*)o = hi;
         *(h8*)(o + a.kp) = a.pattern ? lo : hi;
         *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+        const u4 lb = __builtin_bit_cast(u4, lo);
+        any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
+    if (__syncthreads_or(any_lo) && threadIdx.x == 0) *a.lo_flag = 1;
 }
 
 // operand row = source COLUMN (x^T): 64 x 64 tiles transposed through LDS; K runs over the source rows
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
         T[rr][cc] = v[0]; T[rr][cc + 1] = v[1]; T[rr][cc + 2] = v[2]; T[rr][cc + 3] = v[3];
     }
     __syncthreads();
+    int any_lo = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int w = tid + 256 * i;          // 512 work items: operand row cc (64) x K group kg (8)
@@ -132,7 +138,10 @@ __global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
         *(h8*)o = hi;
         *(h8*)(o + a.kp) = a.pattern ? lo : hi;
         *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+        const u4 lb = __builtin_bit_cast(u4, lo);
+        any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
+    if (__syncthreads_or(any_lo) && tid == 0) *a.lo_flag = 1;
 }
 
 // C[m][n] = sum_y P[y][m][n] (+ bias[n]) (+ resid[m][n]); 16-byte lanes, fixed summation order
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
-                  int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, hipStream_t s) {
+                  int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s) {
     SplitArgs a{};
+    a.lo_flag = lo_flag;
     a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.pattern = pattern; a.trans = trans ? 1 : 0;
     a.amax_bits = amax_bits; a.inv_scale = inv_scale;
     a.rows = trans ? K : op_rows;
@@ -198,7 +208,7 @@ size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
 
 // Worth the four extra small launches (amax + split per operand)?  Only the big products.
 static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
-    if (flags & ~(G32_TA | G32_TB | G32_ACCUM)) return false;            // no activation / dropout epilogues
+    if (flags & ~(G32_TA | G32_TB | G32_ACCUM | G32_HINT_B_EXACT16)) return false;            // no activation / dropout epilogues
     if (p.act_src || p.N % 8 || p.ldc % 4) return false;
     if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return false;
     if (p.lda % 4 || p.ldb % 4) return false;
@@ -222,7 +232,8 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t w
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
     return launch_gemm_x3_any(p, flags, ws, ws_bytes, s);
 }
-static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
+static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_t ws_bytes, hipStream_t s) {
+    int flags = flags_in;
     IISAN_CHECK_SHAPE(x3_shape_ok(p, flags), "gemm_x3: unsupported problem (flags 0x%x, N %d)", flags, p.N);
     IISAN_CHECK_SHAPE(ws && ws_bytes >= gemm_x3_ws_bytes(p.M, p.N, p.K), "gemm_x3: workspace too small");
     const int64_t kp = ceil_div(p.K, 64) * 64, mp = ceil_div(p.M, 128) * 128, np = ceil_div(p.N, 128) * 128;
@@ -233,14 +244,20 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t w
     w += align_up((size_t)np * 3 * kp * 2, 256);
     uint32_t* amax = (uint32_t*)w;            // [0] A, [1] B
     float* inv = (float*)(w + 16);            // [0] A, [1] B
-    IISAN_HIP_OK(hipMemsetAsync(amax, 0, 32, s));
-    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, 0, A16, mp, kp, amax, inv, s));
+    int32_t* lo_flag = (int32_t*)(w + 32);    // [0] A, [1] B: any non-zero lo element
+    IISAN_HIP_OK(hipMemsetAsync(amax, 0, 48, s));
+    // K' = [hi·hi | hi·lo | lo·hi]: the plane that may be all zeros — the lo plane of an operand that is exact in fp16, like
+    // taps cached in fp16 — goes LAST, so the GEMM can drop the last third of K when the device-side flag says so
+    const bool b_last = (flags & G32_HINT_B_EXACT16) != 0;
+    flags &= ~G32_HINT_B_EXACT16;
+    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, b_last ? 1 : 0, A16, mp, kp, amax, inv, lo_flag, s));
     // B operand rows = N: stored [N,K] by default, [K,N] under G32_TB (then the operand is the source transposed)
-    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, 1, B16, np, kp, amax + 1, inv + 1, s));
+    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, b_last ? 0 : 1, B16, np, kp, amax + 1, inv + 1, lo_flag + 1, s));
     Gemm16Args g{};
     g.A = A16; g.W = B16; g.bias = p.bias; g.out = p.C; g.resid = p.resid;
     g.M = p.M; g.N = p.N; g.K = (int32_t)(3 * kp); g.lda = g.ldw = (int32_t)(3 * kp); g.ldo = p.ldc;
     g.inv_a = inv; g.inv_b = inv + 1; g.atomic = 0;
+    g.skip_last_third = lo_flag + (b_last ? 1 : 0);
     const bool accum = (flags & G32_ACCUM) != 0;
     const int ks = x3_ksplit(mp, np, kp);
     if (ks == 1) {

@@ -179,3 +179,25 @@ def test_gemm_x3_matches_fp64(lib, case):
         f32 = f32 + C0
     err32 = (f32.double() - ref).abs().max().item() / scale
     assert err < max(4e-6, 8 * err32), (case, err, err32)
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_gemm_x3_drops_the_zero_lo_plane_of_an_fp16_exact_operand(lib, which):
+    """Taps cached in fp16 are exact in fp16: their lo plane is all zeros, a device-side flag says so and the GEMM skips the
+    last third of K (where that plane's term sits).  Same result as with a genuinely fp32 operand path, to fp32 roundoff."""
+    M, N, K = 1408, 1024, 2048
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(M, K, generator=g) * 0.25
+    B = torch.randn(N, K, generator=g) * 0.02
+    if which == "A":
+        A = A.half().float()
+    else:
+        B = B.half().float()
+    A, B = A.cuda(), B.cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(lib.iisan_gemm_x3_ws_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.iisan_gemm_x3(A.data_ptr(), B.data_ptr(), None, C.data_ptr(), M, N, K, 0, 0, 0, ws.data_ptr(), ws.numel(),
+                                 torch.cuda.current_stream().cuda_stream), "gemm_x3")
+    ref = A.double() @ B.double().t()
+    err = (C.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 4e-6, err
