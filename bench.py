@@ -112,7 +112,7 @@ class Clock:
         if lib is not None:
             lib.iisan_timing_enable(0)
         if self.world > 1:
-            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, out
@@ -254,14 +254,19 @@ class Uncached:
                              f"worst tap layer rel {tap_rel:.2e}")
         return {"loss_auto_dispatch": loss[0], "loss_v1_kernels": loss[1], "loss_rel": rel, "worst_tap_layer_rel": tap_rel}
 
-    def line(self, steps, warmup, dtype="fp16", full_blocks=False, headline=True):
+    def line(self, steps, warmup, dtype="fp16", full_blocks=False, headline=True, overlap=None):
         a, lib, world = self.a, self.lib, self.world
         self.set_dtype(dtype)
         lib.iisan_set_full_blocks(1 if full_blocks else 0)
+        enc = self.model.mm_encoder
+        prev_overlap = enc.overlap_towers
+        if overlap is not None:
+            enc.overlap_towers = overlap
         try:
             elapsed, loss = Clock(self.dev, world).run(self.step, warmup, steps, lib, timed=self.rank == 0)
         finally:
             lib.iisan_set_full_blocks(0)
+            enc.overlap_towers = prev_overlap
         if not torch.isfinite(loss).item():
             raise SystemExit("bench.py: loss is not finite")
         ms, fl = C.c_double(0), C.c_double(0)
@@ -278,7 +283,7 @@ class Uncached:
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        **({"towers": "BERT on a second HIP stream beside ViT (opt-in; per-launch GEMM durations overlap other kernels)"}
-                          if a.overlap_towers else {}),
+                          if (a.overlap_towers if overlap is None else overlap) else {}),
                        "encoder_blocks": "all tokens in every block (as HF)" if full_blocks else
                                          "last block: K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
@@ -399,6 +404,9 @@ def secondary_lines(a, unc, lib, dev, rank, world):
     add("uncached, every block on every token (as HF; SURVEY 8d-clean)", lambda: unc.line(k, w, "fp16", True, headline=False))
     add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", False, headline=False))
     unc.set_dtype(a.dtype)
+    add("uncached, text tower on a second HIP stream beside the image tower (same results; its per-launch GEMM durations overlap "
+        "other kernels, so `roofline` is not a kernel measure here)", lambda: unc.line(k, w, a.dtype, False, headline=False, overlap=True))
+    unc.set_dtype(a.dtype)
     c3 = argparse.Namespace(**{**vars(a), "cached": "fp32", "versa": False, "bs": 1024})
     add("BASELINE config 3: Code_Cached IISAN bs=1024, fp32 tap store", lambda: cached_line(c3, lib, dev, rank, world, 10, 3))
     torch.cuda.empty_cache()
@@ -417,10 +425,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # Test hook (tests/test_gpu_dp.py): IISAN_BENCH_ONE_GPU=1 puts every rank on cuda:0 and IISAN_BENCH_BACKEND=gloo moves the
+    # two collectives through the host — the only way to execute the multi-rank path on a single-GPU box (RCCL refuses two
+    # ranks on one device).  Production: one GPU per rank, backend "nccl" (= RCCL over xGMI).
+    if os.environ.get("IISAN_BENCH_ONE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("IISAN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from iisan_amd import _lib
     lib = _lib.load()

@@ -114,3 +114,24 @@ def test_two_ranks_one_gpu_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_two_ranks_two_gpus_rccl():
     _check(_run_ranks(2, "nccl"), 2)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a rank environment (it used to exit non-zero): the script starts two
+    fresh ranks through torch.distributed.run before touching the GPU, runs warm-up + timed steps of the product DP step
+    (barrier + sync on both sides, MAX over ranks, one gradient all-reduce per step) and rank 0 prints one JSON line.  On
+    this single-GPU box both ranks share cuda:0 and the collectives go through gloo (env test hook of bench.py)."""
+    import json
+    env = dict(os.environ, IISAN_BENCH_ONE_GPU="1", IISAN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bs", "16",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d and "secondary" not in d
