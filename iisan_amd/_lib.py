@@ -86,9 +86,12 @@ SIGNATURES = {
 EXTRA_SIGNATURES = {
     "iisan_timing_enable": (None, [i32]),
     "iisan_set_gemm16_variant": (None, [i32]),
+    "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),
     "iisan_set_x3": (None, [i32]),
     "iisan_set_sanb_fused": (None, [i32]),
+    "iisan_set_sanb_debug": (None, [i32]),
+    "iisan_set_sanb_schedule": (None, [i32, i32]),
     "iisan_set_ce_fast": (None, [i32]),
     "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_set_gemm32_tuning": (None, [i32, i32]),

@@ -254,6 +254,11 @@ int launch_gemm16_w4(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 // Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
 static int g_auto_staggered = 1;
+// 1: the staggered kernel starts its workgroups up to ~one tile time apart on the short-K products with store-heavy
+// epilogues (QKV scatter, FC1 GELU), so the CUs' store bursts stop coinciding (tools/gemm_time.py: QKV 963 -> 988, FC1 900 ->
+// 913 TF; O -2 %, FC2 -7 %: not applied there).  Knob for the A/B (tools/desync_ab.py).
+static int g_desync = 0;
+extern "C" void iisan_set_gemm16_desync(int32_t on) { g_desync = on; }
 extern "C" void iisan_set_gemm16_variant(int v) { g_variant = v; }
 
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
@@ -281,6 +286,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
+        if (g_desync && (mode == EPI_QKVH16 || mode == EPI_GELU16) && a.K <= 1024) b.debug |= 4;
         rc = launch_gemm16_s256(dtype16, mode, b, s);
     } else if (big && gemm16_p256_applicable(a)) {
         Gemm16Args b = a;

@@ -48,7 +48,18 @@ struct SanbArgs {
     SanbTower t[3];
     int64_t M;
     int32_t gelu;
+    int32_t debug;      // ablation bits (iisan_set_sanb_debug): 1 = skip the narrow product, 2 = skip the wide product
+    int32_t stagger;    // start delay of tower y's workgroups: y * stagger * ~4 us (see launch_sanb)
 };
+
+// Workgroups are persistent (grid.x = one per CU and tower, each walks its tiles).  Ablation at the Cached batch size
+// (tools/sanb_ablate.py): 93 us of a launch are its HBM phases, 64 us its two products — the sum is the measured 157 us, i.e.
+// the phases of the three co-resident workgroups do NOT overlap: they start together and stay in lock-step.  A one-off start
+// offset per tower (this function) was tried and is off by default: 2 / 4 / 8 units of ~4 us made the Cached step 6.55 /
+// 6.75 / 6.80 ms against 6.51 — at 150 us per launch the delay costs more than the overlap returns.
+__device__ __forceinline__ void stagger(int units) {
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+}
 
 // LDS: tile [16][D+2] | [16][66]
 __host__ __device__ constexpr int lds_floats(int D) { return R * (D + 2) + R * UST; }
@@ -127,9 +138,12 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     float* Fs = smem;                 // [16][D + 2]   F, then O in place
     float* As = smem + R * FS;        // [16][66]      act(U)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
+    stagger(args.stagger * (int)blockIdx.y);
+    const int64_t ntiles = (args.M + R - 1) / R;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * R;
 
     // ---- 1. fused input tile -> LDS and HBM.  Loads of CH iterations are issued together: one HBM round trip per CH ----
     constexpr int IT = R * d4 / NT, CH = IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : 1);
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
 
     // ---- 2. U = F · Wd^T + bd ; A = act(U) : one 16 x 16 fragment per wave -----------------------------------------
     {
-        const f4 u4 = narrow_product<D>(Fs, t.Wd, wave, lane);
+        const f4 u4 = (args.debug & 1) ? (f4){0.f, 0.f, 0.f, 0.f} : narrow_product<D>(Fs, t.Wd, wave, lane);
         const int col = wave * 16 + (lane & 15);
         const float bd = t.bd[col];
 #pragma unroll
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     __syncthreads();
 
     // ---- 3. O = A · Wu^T + bu + F, in place in LDS -----------------------------------------------------------------
-    wide_product<D>(Fs, As, t.Wu, t.bu, wave, lane);
+    if (!(args.debug & 2)) wide_product<D>(Fs, As, t.Wu, t.bu, wave, lane);
     __syncthreads();
 
     // ---- 4. tile -> HBM, full rows -----------------------------------------------------------------------------------
@@ -196,6 +210,8 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
         const f2* fp = (const f2*)(Fs + row * FS + c);
         const f2 lo = fp[0], hi = fp[1];
         *(f4*)(t.O + m * D + c) = (f4){lo[0], lo[1], hi[0], hi[1]};
+    }
+    __syncthreads();          // the tile buffer is rewritten by the next tile's phase 1
     }
 }
 
@@ -209,9 +225,13 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     float* Gs = smem;                 // [16][D + 2]  dO, then dF in place
     float* Ds = smem + R * FS;        // [16][66]     dU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * R;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
+    stagger(args.stagger * (int)blockIdx.y);
+    const int64_t ntiles = (args.M + R - 1) / R;
+    float gate_part = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t m0 = tile * R;
 
     // ---- 1. dO tile -> LDS (all loads of a thread in flight together) -----------------------------------------------------
     constexpr int IT = R * d4 / NT, CH = IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : 1);
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
 
     // ---- 2. dU = (dO · Wu) ⊙ act'(U) -> LDS and HBM ------------------------------------------------------------------
     {
-        const f4 da = narrow_product<D>(Gs, t.Wd, wave, lane);
+        const f4 da = (args.debug & 1) ? (f4){0.f, 0.f, 0.f, 0.f} : narrow_product<D>(Gs, t.Wd, wave, lane);
         const int col = wave * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     }
 
     // ---- 3. dF = dO + dU · Wd, in place in LDS ---------------------------------------------------------------------------
-    wide_product<D>(Gs, Ds, t.Wu, nullptr, wave, lane);
+    if (!(args.debug & 2)) wide_product<D>(Gs, Ds, t.Wu, nullptr, wave, lane);
     __syncthreads();
 
     // ---- 4. gate gradient, dprev (and the dim-align gradients) with full-row accesses ---------------------------------------
@@ -307,9 +327,12 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
             }
         }
     }
-    if (gated) {
-        part = wave_sum(part);
-        if (lane == 0) red[wave] = part;
+    gate_part += part;
+    __syncthreads();          // the tile buffers are rewritten by the next tile's phase 1
+    }
+    if (gated) {              // one atomic per workgroup for all its tiles
+        gate_part = wave_sum(gate_part);
+        if (lane == 0) red[wave] = gate_part;
         __syncthreads();
         if (tid == 0) atomicAdd(t.dgate, (red[0] + red[1] + red[2] + red[3]) * g * (1.f - g) / 0.1f);
     }
@@ -351,17 +374,27 @@ static void fill(SanbTower& t, const SanbTowerDesc& d) {
     t.dO = d.dO; t.Upre = d.Upre; t.dU = d.dU; t.dprev = d.dprev; t.da = d.da; t.db = d.db; t.dgate = d.dgate; t.dbu = d.dbu; t.dbd = d.dbd;
 }
 
+static int g_sanb_debug = 0, g_sanb_stagger = 0, g_sanb_persist = 1;
+extern "C" void iisan_set_sanb_debug(int32_t bits) { g_sanb_debug = bits; }
+extern "C" void iisan_set_sanb_schedule(int32_t persistent, int32_t stagger_units) { g_sanb_persist = persistent; g_sanb_stagger = stagger_units; }
+
 template <bool BWD>
 static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) {
     IISAN_CHECK_SHAPE(n >= 1 && n <= 3 && M > 0, "sanb: 1..3 towers per launch");
     SanbArgs a{};
-    a.M = M; a.gelu = gelu;
+    a.M = M; a.gelu = gelu; a.debug = g_sanb_debug & 15; a.stagger = g_sanb_stagger;
     const int D = towers[0].D;
     for (int i = 0; i < n; ++i) {
         IISAN_CHECK_SHAPE(towers[i].D == D && sanb_fused_ok(D, RD), "sanb: towers of one launch must share a supported width");
         fill(a.t[i], towers[i]);
     }
-    const dim3 grid((unsigned)ceil_div(M, R), (unsigned)n), block(NT);
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t ntile = ceil_div(M, R);
+    // persistent: one workgroup per CU and tower (three co-resident per CU), each walking tiles x, x + grid.x, ...
+    const unsigned gx = (unsigned)((g_sanb_persist && ntile > cus) ? cus : ntile);
+    const dim3 grid(gx, (unsigned)n), block(NT);
     const size_t lds = lds_bytes(D);
 #define SANB_LAUNCH(DD)                                                                                                \
     do {                                                                                                               \
