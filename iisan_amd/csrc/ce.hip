@@ -28,6 +28,7 @@ struct CeBufs {
     float* lse;      // [T]
     float* rowloss;  // [T]
     float* nvalid;   // [1]
+    float* dprec;    // [T, E] d loss / d prec for d_loss = 1, left by the fused forward pass (ce_rowpass_kernel<CE_FUSED>)
 };
 
 void carve(WsCarver& c, CeBufs& b, int64_t bs, int S) {
@@ -38,6 +39,7 @@ void carve(WsCarver& c, CeBufs& b, int64_t bs, int S) {
     b.lse = c.take<float>(T);
     b.rowloss = c.take<float>(T);
     b.nvalid = c.take<float>(4);
+    b.dprec = c.take<float>(T * E);
 }
 
 __global__ void ce_prep_kernel(const int64_t* __restrict__ ids, const float* __restrict__ log_mask,
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool id_in_seq(const int* __restrict__ ids32, int64_t
     return hit;
 }
 
-enum { CE_FWD = 0, CE_DPREC = 1, CE_DSCORE = 2 };
+enum { CE_FWD = 0, CE_DPREC = 1, CE_DSCORE = 2, CE_FUSED = 3 };
 
 // X rows: prec (FWD, DPREC) or score (DSCORE).  Y rows: the other matrix.
 // RS1: slots per sequence held in registers by the row-fixed passes (11 = the reference's max_seq_len 10 + 1: five fewer
@@ -162,7 +164,10 @@ __global__ __launch_bounds__(256) void ce_pass_kernel(const float* __restrict__ 
     int* myRow = sRow[wave];
     const float dscale = MODE == CE_DSCORE ? d_loss / b.nvalid[0] : 0.f;
 
-    float run_m = -INFINITY, run_l = 0.f, zlab = 0.f;
+    // CE_FUSED: forward and d_prec in ONE pass, flash-attention style: the accumulators hold sum_y exp(z - run_m) * score[y]
+    // against a running ROW maximum (common to the four lanes of a row, because the MFMA sums over their columns) and are
+    // rescaled when it moves — after the first tiles it almost never does, and the test is one ballot per tile.
+    float run_m = MODE == CE_FUSED ? -3.0e38f : -INFINITY, run_l = 0.f, zlab = 0.f;
     f4 dacc[4];
 #pragma unroll
     for (int et = 0; et < 4; ++et) dacc[et] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -391,7 +396,7 @@ template <int MODE, int RS1>
 __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict__ prec, const float* __restrict__ score,
                                                          const float* __restrict__ log_mask, CeBufs b, int bs, int S,
                                                          float d_loss, float* __restrict__ dX) {
-    static_assert(MODE == CE_FWD || MODE == CE_DPREC, "row-fixed passes only");
+    static_assert(MODE == CE_FWD || MODE == CE_DPREC || MODE == CE_FUSED, "row-fixed passes only");
     __shared__ __attribute__((aligned(16))) float sY[4][16 * YLD];
     __shared__ float sRed[4][16][E + 4];
     __shared__ __attribute__((aligned(16))) int sMeta[4][64];
@@ -429,7 +434,10 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
         for (int p = 0; p < RS1; ++p) sid[p] = (p < S1 && sq < bs) ? b.ids32[sq * S1 + p] : -2;
     }
 
-    float run_m = -INFINITY, run_l = 0.f, zlab = 0.f;
+    // CE_FUSED: forward and d_prec in ONE pass, flash-attention style: the accumulators hold sum_y exp(z - run_m) * score[y]
+    // against a running ROW maximum (common to the four lanes of a row, because the MFMA sums over their columns) and are
+    // rescaled when it moves — after the first tiles it almost never does, and the test is one ballot per tile.
+    float run_m = MODE == CE_FUSED ? -3.0e38f : -INFINITY, run_l = 0.f, zlab = 0.f;
     f4 dacc[4];
 #pragma unroll
     for (int et = 0; et < 4; ++et) dacc[et] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             const bool masked = ((pad4 >> r) & 1u) | (((hit4 >> r) & 1u) & (is_lab ? 0u : 1u));
             const float val = masked ? MASKV : z[r] - deb4[r];
             const bool yok = whole || (y0 + 4 * g + r < NY);
-            if (MODE == CE_FWD) {
+            if (MODE == CE_FWD || MODE == CE_FUSED) {
                 fv[r] = yok ? val : -INFINITY;
                 if (yok && is_lab) zlab = val;
             } else {
@@ -523,6 +531,24 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
                 run_m = mn;
             }
         } else {
+            if (MODE == CE_FUSED) {
+                const float m4 = fmaxf(fmaxf(fv[0], fv[1]), fmaxf(fv[2], fv[3]));
+                if (__ballot(m4 > run_m)) {              // wave-uniform and rare
+                    float mr = fmaxf(m4, __shfl_xor(m4, 16, 64));
+                    mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+                    const float mn = fmaxf(run_m, mr);
+                    const float f = fexp(run_m - mn);    // run_m starts at -3e38: f = 0 on the first tile
+                    run_l *= f;
+#pragma unroll
+                    for (int et = 0; et < 4; ++et) dacc[et] *= f;
+                    run_m = mn;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dz[r] = fexp(fv[r] - run_m);         // structural padding: exp(-inf) = 0
+                    run_l += dz[r];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -564,6 +590,47 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             b.lse[x] = lse;
             b.rowloss[x] = row_valid ? lse - zl : 0.f;
         }
+    } else if (MODE == CE_FUSED) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            run_l += __shfl_xor(run_l, o, 64);
+            zlab += __shfl_xor(zlab, o, 64);
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sRed[wave][j][16 * et + 4 * g + r] = dacc[et][r];
+        if (g == 0) {
+            sRed[wave][j][E] = run_m;
+            sRed[wave][j][E + 1] = run_l;
+            sRed[wave][j][E + 2] = zlab;
+        }
+        __syncthreads();
+        // per row: the four waves' partial sums brought to the common maximum; d_prec = (sum_y p_y score_y - score_label) / n
+        for (int i = tid; i < 16 * E; i += 256) {
+            const int rj = i / E, e = i - rj * E;
+            const int xr = x0 + rj;
+            if (xr >= NX) continue;
+            float m = sRed[0][rj][E];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) m = fmaxf(m, sRed[w][rj][E]);
+            float l = 0.f, acc = 0.f, zl = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = fexp(sRed[w][rj][E] - m);
+                l += sRed[w][rj][E + 1] * f;
+                acc += sRed[w][rj][e] * f;
+                zl += sRed[w][rj][E + 2];
+            }
+            const bool valid = log_mask[xr] != 0.f;
+            const int sq = xr / S, lab = sq * S1 + (xr - sq * S) + 1;
+            b.dprec[(int64_t)xr * E + e] = valid ? (acc / l - Y[(int64_t)lab * E + e]) / b.nvalid[0] : 0.f;
+            if (e == 0) {
+                const float lse = m + logf(l);
+                b.lse[xr] = lse;
+                b.rowloss[xr] = valid ? lse - zl : 0.f;
+            }
+        }
     } else {
 #pragma unroll
         for (int et = 0; et < 4; ++et)
@@ -574,6 +641,14 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             const int rj = i / E, e = i - rj * E;
             if (x0 + rj < NX) dX[(int64_t)(x0 + rj) * E + e] = sRed[0][rj][e] + sRed[1][rj][e] + sRed[2][rj][e] + sRed[3][rj][e];
         }
+    }
+}
+
+__global__ void ce_scale_kernel(const float* __restrict__ in, float scale, float* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f4 v = ((const f4*)in)[i];
+        v *= scale;
+        ((f4*)out)[i] = v;
     }
 }
 
@@ -724,7 +799,8 @@ __global__ __launch_bounds__(256) void ce_colpass_kernel(const float* __restrict
     }
 }
 
-// 1 (default): FWD / DPREC on ce_rowpass_kernel when the shape allows; 0: the generic kernel everywhere (test knob)
+// 1 (default): one fused FWD + DPREC row pass (online softmax) and the cooperative column pass; 2: separate FWD and DPREC
+// row passes (round-2a form); 0: the generic kernel everywhere (test knob)
 int g_ce_fast = 1;
 bool rowpass_ok(int64_t bs, int S) { return g_ce_fast && S >= 5 && S + 1 <= MAXS1 && bs * (int64_t)(S + 1) < (1ll << 31); }
 
@@ -763,7 +839,12 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();
-    if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_FWD, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
+    // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it
+    if (rowpass_ok(bs, S) && g_ce_fast == 1 && S + 1 <= 11)
+        hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
+    else if (rowpass_ok(bs, S) && g_ce_fast == 1)
+        hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
+    else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_FWD, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
     else if (rowpass_ok(bs, S)) hipLaunchKernelGGL((ce_rowpass_kernel<CE_FWD, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
@@ -790,7 +871,9 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_DPREC, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
+    if (rowpass_ok(bs, S) && g_ce_fast == 1)
+        hipLaunchKernelGGL(ce_scale_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(T * E / 4, 256), 1024)), dim3(256), 0, s, b.dprec, d_loss, d_prec, T * E / 4);
+    else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_DPREC, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, d_loss, d_prec);
     else if (rowpass_ok(bs, S)) hipLaunchKernelGGL((ce_rowpass_kernel<CE_DPREC, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, d_loss, d_prec);

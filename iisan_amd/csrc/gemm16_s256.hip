@@ -328,6 +328,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
+    if (p.debug & 8) {                         // experiment: one phase per XCD (L2 sharing inside an XCD is kept), spread over
+        const int units = (int)(blockIdx.x & 7) * nk * ((p.debug >> 8) & 15) / 12;     // (debug>>8)&15 kilo-cycles per XCD at K=768
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     if (p.bias)
         for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias[i];
     __syncthreads();

@@ -575,13 +575,13 @@ def test_versa_at_baseline_config5_widths_matches_oracle(x3_mode):
     assert worst > 0.0
 
 
-@pytest.mark.parametrize("ce_fast", [1, 0])
+@pytest.mark.parametrize("ce_fast", [1, 2, 0])
 def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
     """BASELINE config C3 (Cached, bs = 1024): logits [10240, 11264].  The fused loss and both gradients against the
     reference's formula (`model.py:81-104`, as restated in oracle.inbatch_logits) evaluated in fp64 on the device —
     the oracle itself is CPU-sized; its formula is checked against the reference goldens at small sizes."""
     from iisan_amd import synth
-    lib.iisan_set_ce_fast(ce_fast)        # 1 = product default (ce_rowpass_kernel for the row-fixed passes), 0 = generic kernel
+    lib.iisan_set_ce_fast(ce_fast)        # 1 = product default (fused online-softmax row pass), 2 = separate FWD / DPREC row passes, 0 = generic kernel
     bs, S, E = 1024, 10, 64
     b = synth.scientific_batch(bs=bs, seed=77, res=2, words=2, dup_items=True)     # ids / log_mask / pop_prob (tiny content)
     g = torch.Generator().manual_seed(5)
