@@ -218,8 +218,10 @@ static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
 // Below this many FLOPs the extra passes (memset, amax + split per operand, ~7 dependent launches) cost more than the
 // matrix rate gains.  Measured (tools/x3_time.py, MI355X; gemm32 reaches 83-98 TF on these shapes):
 //   [11264,768]x[768,768] fwd / dX 106 us vs 151-160 (1.4-1.5x), its dW 135 vs 160 (1.2x), Versa dim-align [1408,8192]->1024
-//   172 vs 265 (1.5x) and its dW 133 vs 241 (1.8x); [1408,768]x[768,768] 43 vs 30 us (0.7x: stays on the f32 cores).
-static double g_x3_min_flops = 8e9;
+//   172 vs 265 (1.5x) and its dW 133 vs 241 (1.8x); [4373,768]x[768,768] (the distinct ids of a bs = 1024 batch) 61 vs 86
+//   (1.4x), its dW 74 vs 75; [2816,768]x[768,768] 54 vs 50-55 (even); [1408,768]x[768,768] 45 vs 30 us (0.7x: stays on
+//   the f32 cores).
+static double g_x3_min_flops = 4e9;
 void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f; }
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
     return x3_shape_ok(p, flags) && 2.0 * (double)p.M * (double)p.N * (double)p.K >= g_x3_min_flops;

@@ -167,7 +167,8 @@ class ModelMM(nn.Module):                          # model.py:14-105
         self.com_dense = nn.Linear(args.embedding_dim * 3, args.embedding_dim)     # model.py:36-37
         self.criterion = nn.CrossEntropyLoss()
         # opt-in (not reference behaviour): encode each distinct item id of a batch once (padding = id 0), see
-        # IISANAdaptedMModel.forward_item3.  Requires inputs that are a function of the id, as the datasets produce.
+        # IISANAdaptedMModel.forward_item3 (Uncached) and score_embs below (Cached with tap stores).  Requires inputs that
+        # are a function of the id, as the datasets produce.
         self.dedup_items = False
         # Cached path only: packed device tap stores (iisan_amd.tapstore.TapStore) for image / text taps.
         # When set, forward() ignores the `sample_items_images/text` arguments and gathers the taps by item id.
@@ -177,6 +178,14 @@ class ModelMM(nn.Module):                          # model.py:14-105
         enc = self.mm_encoder
         if self.tap_stores is not None and getattr(enc, "cached", False) and sample_items_id is not None:
             st_cv, st_tx = self.tap_stores
+            if self.dedup_items:
+                # opt-in (SURVEY 8f-3 carried over to the Cached path): the side network and com_dense run once per DISTINCT
+                # item id of the batch — on Scientific-shaped batches 57 % of the slots are padding (id 0) and ~11 % of the
+                # rest repeat — and the [U, E] result is gathered back to the [M, E] slots.  Rows are independent and
+                # bit-reproducible, so the loss is bit-identical; gradients differ by summation order only.
+                uniq, inverse = torch.unique(sample_items_id.reshape(-1), return_inverse=True)
+                item3, _ = enc.forward_item3_packed(st_cv.gather(uniq), st_tx.gather(uniq))
+                return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias).index_select(0, inverse)
             item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id))
         elif hasattr(enc, "forward_item3"):
             if self.dedup_items and sample_items_id is not None and not getattr(enc, "cached", False):

@@ -497,6 +497,18 @@ def test_packed_tap_store_feeds_the_cached_model(store):
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert torch.allclose(p.grad, g_ref[k], rtol=1e-4, atol=1e-7), k
+    # opt-in `dedup_items` on the store path: side network + com_dense once per DISTINCT id of the batch (padding included),
+    # gathered back to the slots — the loss stays bit-identical, gradients equal up to summation order
+    assert ids.unique().numel() < ids.numel()
+    m.zero_grad()
+    m.dedup_items = True
+    l_dd = m(ids, None, None, b.log_mask.cuda(), None)
+    l_dd.backward()
+    assert torch.equal(l_ref, l_dd)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            err = (p.grad - g_ref[k]).abs().max().item()          # (sums over unique rows instead of slots: against the tensor's scale)
+            assert err <= 2e-4 * g_ref[k].abs().max().item() + 1e-7, (k, err)      # gate gradients: sums of cancelling dot products
 
 
 @pytest.mark.parametrize("variant", ["text_wide_long", "equal_rmfirst"])

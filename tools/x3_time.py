@@ -13,6 +13,12 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 
 CASES = [  # name, M, N, K, ta, tb, acc
+    ("fc fwd  [4373,768]x[768,768]", 4373, 768, 768, 0, 0, 0),
+    ("fc dX   [4373,768]x[768,768]", 4373, 768, 768, 0, 1, 0),
+    ("fc dW   [768,4373]x[4373,768]", 768, 768, 4373, 1, 1, 1),
+    ("fc fwd  [2816,768]x[768,768]", 2816, 768, 768, 0, 0, 0),
+    ("fc dX   [2816,768]x[768,768]", 2816, 768, 768, 0, 1, 0),
+    ("fc dW   [768,2816]x[2816,768]", 768, 768, 2816, 1, 1, 1),
     ("fc fwd  [11264,768]x[768,768]", 11264, 768, 768, 0, 0, 0),
     ("fc dX   [11264,768]x[768,768]", 11264, 768, 768, 0, 1, 0),
     ("fc dW   [768,11264]x[11264,768]", 768, 768, 11264, 1, 1, 1),
