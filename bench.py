@@ -418,6 +418,9 @@ def secondary_lines(a, unc, lib, dev, rank, world):
     torch.cuda.empty_cache()
     c5 = argparse.Namespace(**{**vars(a), "cached": "fp16", "versa": True, "bs": 128})
     add("BASELINE config 5 shapes on one GPU: IISAN-Versa bs=128, fp16 tap stores", lambda: cached_line(c5, lib, dev, rank, world, 10, 3))
+    c5d = argparse.Namespace(**{**vars(c5), "dedup": True})
+    add("IISAN-Versa bs=128 with the side network on DISTINCT item ids only (opt-in, loss bit-identical; reported separately)",
+        lambda: cached_line(c5d, lib, dev, rank, world, 10, 3))
     return out
 
 

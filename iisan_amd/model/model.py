@@ -184,6 +184,9 @@ class ModelMM(nn.Module):                          # model.py:14-105
                 # rest repeat — and the [U, E] result is gathered back to the [M, E] slots.  Rows are independent and
                 # bit-reproducible, so the loss is bit-identical; gradients differ by summation order only.
                 uniq, inverse = torch.unique(sample_items_id.reshape(-1), return_inverse=True)
+                pad = (-uniq.numel()) % 64         # whole 64-row tiles for the K = rows weight-gradient products; the extra
+                if pad:                            # rows (copies of the first id) are gathered by nobody: zero gradient
+                    uniq = torch.cat([uniq, uniq[:1].expand(pad)])
                 item3, _ = enc.forward_item3_packed(st_cv.gather(uniq), st_tx.gather(uniq))
                 return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias).index_select(0, inverse)
             item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id))
