@@ -94,6 +94,7 @@ EXTRA_SIGNATURES = {
     "iisan_set_sanb_schedule": (None, [i32, i32]),
     "iisan_set_ce_fast": (None, [i32]),
     "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
+    "iisan_set_gemm32_accum_scratch": (None, [i32]),
     "iisan_set_gemm32_tuning": (None, [i32, i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),

@@ -332,10 +332,12 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int 
 
 float* g_scratch = nullptr;
 size_t g_scratch_floats = 0;
+int g_accum_via_scratch = 1;       // 0: weight-gradient split-K sums by atomics (test / bench knob, iisan_set_gemm32_tuning)
 
 // launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
 // before split-K stops adding slices
 static int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
+extern "C" void iisan_set_gemm32_accum_scratch(int32_t on) { g_accum_via_scratch = on; }
 extern "C" void iisan_set_gemm32_tuning(int32_t tm_thresh, int32_t splitk_target) {
     g_tm_thresh = tm_thresh > 0 ? tm_thresh : 512;
     g_splitk_target = splitk_target > 0 ? splitk_target : 1024;
@@ -414,6 +416,40 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
             via_scratch = true;
         }
     }
+    // Weight-gradient products ("+=", K = number of item slots): the split-K partial products used to be added with fp32
+    // atomics — 29 splits x 49k outputs x 3 towers = 4.3 M atomics per launch, which is what the launch took (45 us at
+    // K = 11264 and 48 us at K = 4373: independent of K; rocprofv3, Cached step).  Through the scratch buffer instead: plain
+    // 16-byte stores of the partials and a reducer that adds them to C in a fixed order — faster, and the weight gradients
+    // become bit-reproducible.  Falls back to atomics when the scratch buffer is missing or too small.
+    int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
+    if ((flags & G32_ACCUM) && g_scratch && g_accum_via_scratch && splitk >= 2) {
+        {   // only NON-EMPTY K ranges: the kernel gives split y the K-tiles [y, y+1) * ceil(ktiles / splits) and a split whose
+            // range is empty writes nothing — its partial would be read uninitialised by the reducer
+            const int64_t ktiles = ceil_div(min_k, (int64_t)TK), per = ceil_div(ktiles, (int64_t)splitk);
+            splitk = (int)ceil_div(ktiles, per);
+        }
+        int64_t need = 0;
+        bool same_k = true;
+        for (int i = 0; i < nprob; ++i) {
+            need += (int64_t)splitk * (int64_t)align_up((size_t)(probs[i].M * probs[i].N), 64);
+            same_k = same_k && probs[i].K == probs[0].K;
+        }
+        if ((size_t)need <= g_scratch_floats) {
+            int64_t off = 0;
+            for (int i = 0; i < nprob; ++i) {
+                Gemm32Prob& q = b.p[i];
+                q.C = g_scratch + off; q.ldc = q.N; q.bias = nullptr; q.resid = nullptr; q.act_src = nullptr;
+                q.ksplit_stride = (int64_t)align_up((size_t)(q.M * q.N), 64);
+                off += splitk * q.ksplit_stride;
+                orig.p[i].resid = orig.p[i].C;          // the reducer adds the old C:  C = sum of partials + C
+                orig.p[i].ldr = orig.p[i].ldc;
+                orig.p[i].bias = nullptr;
+            }
+            if (!same_k) IISAN_HIP_OK(hipMemsetAsync(g_scratch, 0, (size_t)need * sizeof(float), s));   // a K-split beyond a short problem's K writes nothing
+            via_scratch = true;
+            structural &= ~G32_ACCUM;
+        }
+    }
     dim3 grid((unsigned)max_tiles, (unsigned)splitk, (unsigned)nprob);
     // FAST fetch: full tiles, whole K-tiles per split, 16-byte aligned operand rows — for every problem of the launch
     bool fast = true;
@@ -422,8 +458,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
         fast = q.M % TM == 0 && q.N % TN == 0 && q.K % TK == 0 &&
                (q.lda & 3) == 0 && (q.ldb & 3) == 0 && ((uintptr_t)q.A & 15) == 0 && ((uintptr_t)q.B & 15) == 0;
     }
-    const int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
-    const int epi = via_scratch ? 0 : (flags & ~structural);
+    const int epi = via_scratch ? 0 : (flags & ~(G32_TA | G32_TB | G32_ACCUM));
     int rc;
     switch (structural) {
 #define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, s); break
@@ -449,7 +484,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     }
     int64_t blocks = ceil_div(max_mn, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)blocks, 1, (unsigned)nprob), dim3(256), 0, s, rb, splitk, flags & ~structural);
+    hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)blocks, 1, (unsigned)nprob), dim3(256), 0, s, rb, splitk, flags & ~(G32_TA | G32_TB | G32_ACCUM));
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

@@ -253,6 +253,11 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         b.WT[z][1] = c.take<float>((size_t)p.D[z] * p.r);
     }
     b.skws_floats = (size_t)3 * 8 * align_up((size_t)M * p.r, 64);     // three towers x 8 K-splits x [M, down]
+    {   // ... and the split-K partials of the adapters' weight-gradient products: three towers x <= 32 splits x [D, down]
+        size_t wg = 0;
+        for (int z = 0; z < 3; ++z) wg += (size_t)32 * align_up((size_t)p.D[z] * p.r, 64);
+        if (wg > b.skws_floats) b.skws_floats = wg;
+    }
     b.skws = c.take<float>(b.skws_floats);
     b.x3_bytes = x3_need(p, M);
     b.x3 = b.x3_bytes ? (void*)c.take<char>(b.x3_bytes) : nullptr;

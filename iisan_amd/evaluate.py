@@ -36,7 +36,8 @@ def build_tap_cache(model, images: torch.Tensor, text: torch.Tensor, batch: int 
 @torch.no_grad()
 def item_table(model, images_or_taps: torch.Tensor, text_or_taps: torch.Tensor, batch: int = 512, rank: int = 0,
                world: int = 1) -> torch.Tensor:
-    """Item embedding table `com_dense(cat(cv, text, mm))` [N, emb] for items 0..N-1 (row 0 = the padding item)."""
+    """Item embedding table `com_dense(cat(cv, text, mm))` (modality 'inter': `com_dense(mm)`) [N, emb] for items 0..N-1
+    (row 0 = the padding item)."""
     N = images_or_taps.shape[0]
     per = (N + world - 1) // world
     lo, hi = min(rank * per, N), min((rank + 1) * per, N)
@@ -44,7 +45,7 @@ def item_table(model, images_or_taps: torch.Tensor, text_or_taps: torch.Tensor, 
     for i in range(lo, hi, batch):
         j = min(i + batch, hi)
         item3, _ = model.mm_encoder.forward_item3(images_or_taps[i:j].contiguous(), text_or_taps[i:j].contiguous())
-        rows.append(ops.LinearFn.apply(item3, model.com_dense.weight, model.com_dense.bias))
+        rows.append(model.fuse_item3(item3))
     emb = model.com_dense.weight.shape[0]
     mine = torch.cat(rows) if rows else torch.empty(0, emb, device=images_or_taps.device)
     if world == 1:
@@ -112,19 +113,22 @@ def print_metrics(x, Log_file, v_or_t):
 def eval_model(model, user_history, eval_seq, item_embeddings_image, item_embeddings_text, test_batch_size, args, item_num,
                Log_file, v_or_t, local_rank):
     """Same signature, log lines and return value (Hit@10) as the reference's `eval_model` (`metrics.py:157-246`),
-    for `modality == "intra_inter"`: `item_embeddings_text` is the pair `[text, inter]` that
-    `get_MM_item_embeddings` returns.  `eval_seq` maps user index -> item sequence (last = target), `user_history[u]`
+    for the modalities the IISAN wrapper serves: `item_embeddings_text` is the pair `[text, inter]` that
+    `get_MM_item_embeddings` returns; with `modality == "inter"` only `inter` is read (`metrics.py:175-178,192-199`).  `eval_seq` maps user index -> item sequence (last = target), `user_history[u]`
     the items whose scores are set to -inf.  Works with or without an initialised process group; with one, users are
     sharded like `SequentialDistributedSampler` and the ranks gathered on every rank."""
-    if "inter" not in args.modality or "intra" not in args.modality:
-        raise NotImplementedError("eval_model: only modality 'intra_inter' is on the hot path")
+    if "inter" not in args.modality:
+        raise NotImplementedError("eval_model: modality 'intra' is not served by the IISAN wrapper")
     m = model.module if hasattr(model, "module") else model
     text, inter = item_embeddings_text
     dev = torch.device("cuda", local_rank) if isinstance(local_rank, int) else torch.device(local_rank)
     topK = 10
     Log_file.info(v_or_t + "_methods   {}".format('\t'.join(['Hit{}'.format(topK), 'nDCG{}'.format(topK)])))
     m.eval()
-    item3 = torch.cat([item_embeddings_image.to(dev), text.to(dev), inter.to(dev)], dim=1).float().contiguous()
+    if args.modality == "inter":
+        item3 = inter.to(dev).float().contiguous()                                      # metrics.py:175-178
+    else:
+        item3 = torch.cat([item_embeddings_image.to(dev), text.to(dev), inter.to(dev)], dim=1).float().contiguous()
     item_emb = ops.LinearFn.apply(item3, m.com_dense.weight, m.com_dense.bias)          # metrics.py:181
     users = range(len(eval_seq))
     seqs = [list(eval_seq[u]) for u in users]

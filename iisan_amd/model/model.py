@@ -25,27 +25,37 @@ class _SideNetBase(nn.Module):
         else:                                       # model.py:176-177
             self.side_bert_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
             self.side_cv_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
-        if "intra" not in args.modality or "inter" not in args.modality:
-            raise NotImplementedError(f"modality {args.modality!r}: only the IISAN default 'intra_inter' is built")
+        if "inter" not in args.modality:
+            # the reference wrapper returns (cv, [text, mm]) whatever the modality (model.py:271) and ModelMM's plain 'intra'
+            # branch concatenates cv with that LIST (model.py:73-74): it does not run there either
+            raise NotImplementedError(f"modality {args.modality!r}: the IISAN wrapper serves 'intra_inter' and 'inter'")
         if self.side_bert_adapter_num_list != self.side_cv_adapter_num_list:
             raise NotImplementedError("different tap lists per tower are the Versa variant (Code_Cached_Asym)")
         n = len(self.side_cv_adapter_num_list)
-        self.cv_adapter_list = nn.ModuleList([AdapterBlock(args, embedding_dim, args.cv_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
-        self.bert_adapter_list = nn.ModuleList([AdapterBlock(args, args.word_embedding_dim, args.bert_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
+        # model.py:178-205: the intra-modal towers (cv, text) exist with "intra" in the modality, the inter-modal tower (mm)
+        # with "inter".  With modality "inter" only the mm tower has parameters (and state-dict keys); the fused HIP side
+        # network still runs three towers — the other two on zero placeholders, their outputs unused by ModelMM.
+        self.intra = "intra" in args.modality
+        if self.intra:
+            self.cv_adapter_list = nn.ModuleList([AdapterBlock(args, embedding_dim, args.cv_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
+            self.bert_adapter_list = nn.ModuleList([AdapterBlock(args, args.word_embedding_dim, args.bert_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
         self.mm_adapter_list = nn.ModuleList([AdapterBlock(args, args.word_embedding_dim, args.bert_adapter_down_size, args.adapter_dropout_rate) for _ in range(n)])
-        self.fc_bert = nn.Linear(embedding_dim, embedding_dim)
-        self.fc_cv = nn.Linear(embedding_dim, embedding_dim)
+        if self.intra:
+            self.fc_bert = nn.Linear(embedding_dim, embedding_dim)
+            self.fc_cv = nn.Linear(embedding_dim, embedding_dim)
         self.fc_mm = nn.Linear(args.word_embedding_dim, args.word_embedding_dim)
         self.fc_mm_down = nn.Linear(args.word_embedding_dim, args.embedding_dim)
         self.gated = args.fusion_method == "gated"
         if self.gated:                              # model.py:190-205
-            self.side_gate_params_text = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
-            self.side_gate_params_cv = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
+            if self.intra:
+                self.side_gate_params_text = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
+                self.side_gate_params_cv = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
             self.side_gate_params_mm = nn.ParameterList([nn.Parameter(torch.ones(1) * 0) for _ in range(n)])
         self.args = args
         self.n_side = n
         self.remove_first = args.remove_first == "TRUE"
         self._order = ops.side_param_order(n, cached=self.cached)
+        self._placeholders = {}
 
     def _abi_params(self, device):
         sd = dict(self.named_parameters())
@@ -53,14 +63,27 @@ class _SideNetBase(nn.Module):
         for k in self._order:
             if k in sd:
                 out.append(sd[k])
-            else:                                    # gates do not exist when fusion_method != "gated"
-                assert "side_gate" in k, k
-                out.append(torch.zeros(1, device=device))
+                continue
+            # gates do not exist when fusion_method != "gated"; the cv / text towers do not exist with modality "inter"
+            assert "side_gate" in k or (not self.intra and any(t in k for t in ("cv_adapter_list", "bert_adapter_list", "fc_cv", "fc_bert"))), k
+            ph = self._placeholders.get(k)
+            if ph is None or ph.device != device:
+                shape = (1,) if "side_gate" in k else self._placeholder_shape(k)
+                ph = self._placeholders[k] = torch.zeros(shape, device=device)
+            out.append(ph)
         return out
 
+    def _placeholder_shape(self, k):
+        D, r = self.fc_mm.in_features, self.mm_adapter_list[0].fc_down.out_features
+        if "fc_down.weight" in k: return (r, D)
+        if "fc_down.bias" in k: return (r,)
+        if "fc_up.weight" in k: return (D, r)
+        if "fc_up.bias" in k: return (D,)
+        return (D, D) if k.endswith("weight") else (D,)            # fc_cv / fc_bert
+
     def _side(self, taps_cv, taps_text, tap_index, first_index):
-        cfg = ops.make_side_cfg(self.n_side, taps_cv.shape[-1], self.cv_adapter_list[0].fc_down.out_features,
-                                self.fc_mm_down.out_features, self.gated, self.cv_adapter_list[0].gelu, self.remove_first,
+        cfg = ops.make_side_cfg(self.n_side, taps_cv.shape[-1], self.mm_adapter_list[0].fc_down.out_features,
+                                self.fc_mm_down.out_features, self.gated, self.mm_adapter_list[0].gelu, self.remove_first,
                                 taps_cv.shape[1], taps_text.shape[1], tap_index, first_index)
         item3 = ops.SideNetFn.apply(cfg, taps_cv, taps_text, *self._abi_params(taps_cv.device))
         E = cfg.emb
@@ -162,9 +185,13 @@ class ModelMM(nn.Module):                          # model.py:14-105
         if not use_modal:
             raise NotImplementedError("use_modal=False (ID embeddings) is not the IISAN hot path")
         self.mm_encoder = MM_Encoder(args, image_net, bert_model)
-        if "intra_inter" not in args.modality:
-            raise NotImplementedError(f"modality {args.modality!r}: only 'intra_inter' is built")
-        self.com_dense = nn.Linear(args.embedding_dim * 3, args.embedding_dim)     # model.py:36-37
+        if "inter" not in args.modality:
+            raise NotImplementedError(f"modality {args.modality!r}: 'intra_inter' (IISAN default) and 'inter' are built; plain "
+                                      "'intra' does not run with the IISAN wrapper in the reference either (model.py:73-74)")
+        # model.py:36-41: 'intra_inter' -> com_dense(cat[cv, text, mm]); 'inter' -> com_dense(mm) alone (the cv / text towers
+        # still run, as in the reference, and receive zero gradients)
+        self.inter_only = "intra_inter" not in args.modality
+        self.com_dense = nn.Linear(args.embedding_dim * (1 if self.inter_only else 3), args.embedding_dim)
         self.criterion = nn.CrossEntropyLoss()
         # opt-in (not reference behaviour): encode each distinct item id of a batch once (padding = id 0), see
         # IISANAdaptedMModel.forward_item3 (Uncached) and score_embs below (Cached with tap stores).  Requires inputs that
@@ -188,7 +215,7 @@ class ModelMM(nn.Module):                          # model.py:14-105
                 if pad:                            # rows (copies of the first id) are gathered by nobody: zero gradient
                     uniq = torch.cat([uniq, uniq[:1].expand(pad)])
                 item3, _ = enc.forward_item3_packed(st_cv.gather(uniq), st_tx.gather(uniq))
-                return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias).index_select(0, inverse)
+                return self.fuse_item3(item3).index_select(0, inverse)
             item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id))
         elif hasattr(enc, "forward_item3"):
             if self.dedup_items and sample_items_id is not None and not getattr(enc, "cached", False):
@@ -197,7 +224,14 @@ class ModelMM(nn.Module):                          # model.py:14-105
                 item3, _ = enc.forward_item3(sample_items_images, sample_items_text)
         else:
             raise NotImplementedError("mm_encoder must be wrapped by IISANAdaptedMModel (run.py:214-216)")
-        return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias)             # model.py:67-69
+        return self.fuse_item3(item3)
+
+    def fuse_item3(self, item3):
+        """`com_dense` over the towers' outputs `[M, 3E] = cv | text | mm` (model.py:67-72)."""
+        if self.inter_only:
+            E = self.args.embedding_dim
+            item3 = item3[:, 2 * E:].contiguous()
+        return ops.LinearFn.apply(item3, self.com_dense.weight, self.com_dense.bias)
 
     def forward(self, sample_items_id, sample_items_images, sample_items_text, log_mask, local_rank=None):
         if self.pop_prob_list.device != log_mask.device:

@@ -24,8 +24,8 @@ class VersaIISANAdaptedMModel(nn.Module):
         else:
             self.side_bert_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_bert_list.split(",")]
             self.side_cv_adapter_num_list = [0] + [int(i) + 1 for i in args.side_adapter_vit_list.split(",")]
-        if "intra" not in args.modality or "inter" not in args.modality:
-            raise NotImplementedError(f"modality {args.modality!r}: only 'intra_inter' is built")
+        if "inter" not in args.modality:
+            raise NotImplementedError(f"modality {args.modality!r}: the IISAN wrapper serves 'intra_inter' and 'inter'")
         if args.cv_adapter_down_size != args.bert_adapter_down_size:
             raise NotImplementedError("the HIP side network uses one bottleneck width for all towers")
         n_cv, n_t = len(self.side_cv_adapter_num_list), len(self.side_bert_adapter_num_list)

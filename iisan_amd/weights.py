@@ -280,7 +280,7 @@ def config_dict(cfg) -> dict:
 # ----------------------------------------------------------------------------------------------------------------
 
 def trainable_shapes(n_side: int = 7, dim_cv: int = 768, dim_text: int = 768, down: int = 64, emb: int = 64,
-                     seq_len: int = 10, n_blocks: int = 2, cached: bool = False) -> Dict[str, tuple]:
+                     seq_len: int = 10, n_blocks: int = 2, cached: bool = False, modality: str = "intra_inter") -> Dict[str, tuple]:
     """Shapes of the 146 trainable tensors of IISAN mode in `named_parameters()` order-independent form
     (`Code_Uncached/model/model.py:166-205`, `modules.py:35-116`, `model.py:36-37`)."""
     ue = "user_encoder.transformer_encoder."
@@ -299,23 +299,29 @@ def trainable_shapes(n_side: int = 7, dim_cv: int = 768, dim_text: int = 768, do
         s[f + "w_2.bias"] = (emb,)
         s[f + "layer_norm.weight"] = (emb,)
         s[f + "layer_norm.bias"] = (emb,)
-    s["com_dense.weight"] = (emb, 3 * emb)
+    s["com_dense.weight"] = (emb, 3 * emb if "intra_inter" in modality else emb)       # model.py:36-41 ("inter": the mm tower only)
     s["com_dense.bias"] = (emb,)
     m = "mm_encoder."
     cvh = m + ("cv_pre_fc." if cached else "cv_encoder.image_net.classifier.")
     txh = m + ("bert_pre_fc." if cached else "bert_encoder.text_encoders.title.fc.")
     s[cvh + "weight"], s[cvh + "bias"] = (emb, dim_cv), (emb,)
     s[txh + "weight"], s[txh + "bias"] = (emb, dim_text), (emb,)
+    intra = "intra" in modality                     # model.py:178-205: the cv / text towers exist only with "intra"
     for tower, d in (("cv", dim_cv), ("bert", dim_text), ("mm", dim_text)):
+        if tower != "mm" and not intra:
+            continue
         for k in range(n_side):
             p = m + f"{tower}_adapter_list.{k}."
             s[p + "fc_down.weight"], s[p + "fc_down.bias"] = (down, d), (down,)
             s[p + "fc_up.weight"], s[p + "fc_up.bias"] = (d, down), (d,)
-    s[m + "fc_bert.weight"], s[m + "fc_bert.bias"] = (dim_text, dim_text), (dim_text,)
-    s[m + "fc_cv.weight"], s[m + "fc_cv.bias"] = (dim_cv, dim_cv), (dim_cv,)
+    if intra:
+        s[m + "fc_bert.weight"], s[m + "fc_bert.bias"] = (dim_text, dim_text), (dim_text,)
+        s[m + "fc_cv.weight"], s[m + "fc_cv.bias"] = (dim_cv, dim_cv), (dim_cv,)
     s[m + "fc_mm.weight"], s[m + "fc_mm.bias"] = (dim_text, dim_text), (dim_text,)
     s[m + "fc_mm_down.weight"], s[m + "fc_mm_down.bias"] = (emb, dim_text), (emb,)
     for g in ("text", "cv", "mm"):
+        if g != "mm" and not intra:
+            continue
         for k in range(n_side):
             s[m + f"side_gate_params_{g}.{k}"] = (1,)
     return s

@@ -130,38 +130,44 @@ def side_network(taps_cv: Tensor, taps_text: Tensor, P: Dict[str, Tensor], layer
                  fusion: str = "gated", activation: str = "RELU", remove_first: bool = False,
                  cv_head: str = "mm_encoder.cv_encoder.image_net.classifier.",
                  text_head: str = "mm_encoder.bert_encoder.text_encoders.title.fc.",
-                 pre: str = "mm_encoder.") -> Tuple[Tensor, Tensor, Tensor]:
+                 pre: str = "mm_encoder.", modality: str = "intra_inter") -> Tuple[Tensor, Tensor, Tensor]:
     """taps_* : [M, L+1, D] CLS taps (all hidden states; `layers` selects).  Returns (cv, text, mm), each [M,E].
     `cv_head`/`text_head` name the 768->64 projections (Uncached keys by default; Cached uses
-    `mm_encoder.cv_pre_fc.` / `mm_encoder.bert_pre_fc.`, `Code_Cached/model/model.py:261-262`)."""
+    `mm_encoder.cv_pre_fc.` / `mm_encoder.bert_pre_fc.`, `Code_Cached/model/model.py:261-262`).
+    `modality` "inter" (no "intra"): the cv / text towers do not exist (model.py:178-205,228,253,260) and (None, None, mm)
+    is returned — the reference hands back their untouched initial states, which its ModelMM ignores (model.py:70-72)."""
     zeros = torch.zeros_like(taps_cv[:, 0])
+    intra = "intra" in modality
     if remove_first:                                   # model.py:215-218
         cv, text, mm = taps_cv[:, 0], taps_text[:, 0], zeros
     else:
         cv, text, mm = zeros, zeros, zeros
     for k, l in enumerate(layers):
         tv, tt = taps_cv[:, l], taps_text[:, l]
-        if fusion == "gated":                           # model.py:229-236
-            g = torch.sigmoid(P[pre + f"side_gate_params_cv.{k}"] / 0.1)
-            f_cv = g * tv + (1 - g) * cv
-            g = torch.sigmoid(P[pre + f"side_gate_params_text.{k}"] / 0.1)
-            f_text = g * tt + (1 - g) * text
-        else:                                           # model.py:237-239
-            f_cv, f_text = tv + cv, tt + text
-        text = adapter_block(f_text, P, pre + f"bert_adapter_list.{k}.", activation)
-        cv = adapter_block(f_cv, P, pre + f"cv_adapter_list.{k}.", activation)
+        if intra:
+            if fusion == "gated":                       # model.py:229-236
+                g = torch.sigmoid(P[pre + f"side_gate_params_cv.{k}"] / 0.1)
+                f_cv = g * tv + (1 - g) * cv
+                g = torch.sigmoid(P[pre + f"side_gate_params_text.{k}"] / 0.1)
+                f_text = g * tt + (1 - g) * text
+            else:                                       # model.py:237-239
+                f_cv, f_text = tv + cv, tt + text
+            text = adapter_block(f_text, P, pre + f"bert_adapter_list.{k}.", activation)
+            cv = adapter_block(f_cv, P, pre + f"cv_adapter_list.{k}.", activation)
         if fusion == "gated":                           # model.py:245-250
             g = torch.sigmoid(P[pre + f"side_gate_params_mm.{k}"] / 0.1)
             mm = mm + g * tv + (1 - g) * tt
         else:                                           # model.py:251-252
             mm = mm + tv + tt
         mm = adapter_block(mm, P, pre + f"mm_adapter_list.{k}.", activation)
-    text = F.linear(text, P[pre + "fc_bert.weight"], P[pre + "fc_bert.bias"])      # model.py:253-257
+    mm = F.linear(mm, P[pre + "fc_mm.weight"], P[pre + "fc_mm.bias"])               # model.py:256-257
+    mm = F.linear(mm, P[pre + "fc_mm_down.weight"], P[pre + "fc_mm_down.bias"])     # model.py:268-269
+    if not intra:
+        return None, None, mm
+    text = F.linear(text, P[pre + "fc_bert.weight"], P[pre + "fc_bert.bias"])      # model.py:253-255
     cv = F.linear(cv, P[pre + "fc_cv.weight"], P[pre + "fc_cv.bias"])
-    mm = F.linear(mm, P[pre + "fc_mm.weight"], P[pre + "fc_mm.bias"])
-    cv = F.linear(cv, P[cv_head + "weight"], P[cv_head + "bias"])                    # model.py:260-269
+    cv = F.linear(cv, P[cv_head + "weight"], P[cv_head + "bias"])                    # model.py:260-267
     text = F.linear(text, P[text_head + "weight"], P[text_head + "bias"])
-    mm = F.linear(mm, P[pre + "fc_mm_down.weight"], P[pre + "fc_mm_down.bias"])
     return cv, text, mm
 
 
@@ -292,10 +298,15 @@ def inbatch_ce(ids: Tensor, score: Tensor, prec: Tensor, log_mask: Tensor, pop_p
 
 def model_loss_from_taps(ids: Tensor, taps_cv: Tensor, taps_text: Tensor, log_mask: Tensor, pop_prob: Tensor,
                          P: Dict[str, Tensor], layers: Sequence[int], heads: int = 2, n_layers: int = 2,
-                         **side_kw) -> Tuple[Tensor, Dict[str, Tensor]]:
+                         modality: str = "intra_inter", **side_kw) -> Tuple[Tensor, Dict[str, Tensor]]:
     bs, S = log_mask.shape
-    cv, text, mm = side_network(taps_cv, taps_text, P, layers, **side_kw)
-    score = F.linear(torch.cat([cv, text, mm], 1), P["com_dense.weight"], P["com_dense.bias"])     # model.py:67-69
+    if "inter" not in modality:   # model.py:73-74 concatenates cv with the LIST [text, mm] the IISAN wrapper returns: not runnable in the reference
+        raise NotImplementedError("modality 'intra' does not run with the IISAN wrapper in the reference (model.py:73-74)")
+    cv, text, mm = side_network(taps_cv, taps_text, P, layers, modality=modality, **side_kw)
+    if "intra_inter" in modality:
+        score = F.linear(torch.cat([cv, text, mm], 1), P["com_dense.weight"], P["com_dense.bias"])  # model.py:67-69
+    else:
+        score = F.linear(mm, P["com_dense.weight"], P["com_dense.bias"])                            # model.py:70-72
     E = score.shape[1]
     prec = sasrec(score.view(bs, S + 1, E)[:, :-1], log_mask, P, heads, n_layers).reshape(-1, E)    # model.py:74-77
     loss = inbatch_ce(ids, score, prec, log_mask, pop_prob)

@@ -11,6 +11,7 @@ inputs from `iisan_amd.synth` through, and stores INPUT CHECKSUMS + EXPECTED OUT
                       prec, loss, gradients (small tensors whole, large ones strided), one Adam step; variants
   e2e_small.npz       Uncached ModelMM end to end with 2-layer ViT/BERT (hidden 768): loss + gradients
   e2e_bs8.npz         the same on 8 sequences (88 item slots)
+  e2e_inter.npz       the same as e2e_small with --modality inter (mm tower only)
   eval.npz            data_utils.metrics.eval_model: Hit@10 / nDCG@10 and per-user ranks
   adam_groups.json    name -> Adam group of the 146 trainable tensors under the rule of run.py:296-321
 
@@ -151,7 +152,8 @@ def run_ref_loss(model, ids, img_in, txt_in, log_mask, names):
         p.grad = None
     loss = model(ids.view(-1), img_in, txt_in, log_mask, "cpu")
     loss.backward()
-    grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in names}
+    # (modality "inter": the cv / text towers are outside the loss and keep grad None — they are left out of the fixture)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in names and p.grad is not None}
     return loss.detach(), grads
 
 
@@ -226,7 +228,7 @@ def group_rule():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def gen_e2e_small(name="e2e_small", lengths=(3, 11, 6), write_groups=True):
+def gen_e2e_small(name="e2e_small", lengths=(3, 11, 6), write_groups=True, modality="intra_inter"):
     vcfg = weights.VitConfig(hidden=768, layers=2, heads=12, mlp=512, image=32, patch=16)
     bcfg = weights.BertConfig(hidden=768, layers=2, heads=12, mlp=512, vocab=512, max_pos=64)
     vw, bw = weights.make_vit_weights(vcfg, seed=11), weights.make_bert_weights(bcfg, seed=12)
@@ -235,12 +237,12 @@ def gen_e2e_small(name="e2e_small", lengths=(3, 11, 6), write_groups=True):
     b = synth.scientific_batch(bs=bs, seed=31, lengths=list(lengths), dup_items=True, res=32, words=words,
                                vocab=512, item_num=40)
     ref = load_ref_pkg("Code_Uncached", "model")
-    args = ref_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=words)
+    args = ref_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=words, modality=modality)
     model = ref.ModelMM(args, 40, True, vit, bert, b.pop_prob.numpy())
     for p in model.parameters():
         p.requires_grad_(False)                                               # run.py:177-183
     model.mm_encoder = ref.IISANAdaptedMModel(model.mm_encoder, args)        # run.py:214-216
-    P = weights.make_trainable_params(seed=101, n_side=3)
+    P = weights.make_trainable_params(seed=101, n_side=3, modality=modality)
     missing, unexpected = model.load_state_dict(P, strict=False)
     assert not unexpected, unexpected
     model.eval()
@@ -249,7 +251,9 @@ def gen_e2e_small(name="e2e_small", lengths=(3, 11, 6), write_groups=True):
     with torch.no_grad():
         cv, (text, mm) = model.mm_encoder(b.images, b.text)
     out = dict(ids=b.ids.numpy(), log_mask=b.log_mask.numpy(), text=b.text.numpy(), pop=b.pop_prob.numpy(),
-               images_sha=sha(b.images), loss=loss.numpy(), cv=cv.numpy(), text_emb=text.numpy(), mm=mm.numpy())
+               images_sha=sha(b.images), loss=loss.numpy(), mm=mm.numpy())
+    if "intra" in modality:      # modality "inter": the wrapper returns the untouched 768-wide zero states for cv / text
+        out.update(cv=cv.numpy(), text_emb=text.numpy())
     out.update(pack_grads(grads))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(f"{name}: loss {loss.item():.6f}")
@@ -382,8 +386,14 @@ def gen_e2e_bs8():
     gen_e2e_small("e2e_bs8", E2E_BS8_LENGTHS, write_groups=False)
 
 
+def gen_e2e_inter():
+    """modality "inter" (only the inter-modal tower; model.py:38-39,70-72,182-205).  Runs in Code_Uncached only: the
+    Cached wrapper's forward walks `bert_adapter_list`, which that modality does not create (Code_Cached/model/model.py:318)."""
+    gen_e2e_small("e2e_inter", write_groups=False, modality="inter")
+
+
 GENS = dict(versa=gen_versa, encoders_full=gen_encoders_full, sidenet_full=gen_sidenet_full, e2e_small=gen_e2e_small,
-            e2e_bs8=gen_e2e_bs8, eval=gen_eval)
+            e2e_bs8=gen_e2e_bs8, e2e_inter=gen_e2e_inter, eval=gen_eval)
 
 if __name__ == "__main__":
     import importlib.machinery  # noqa: F401

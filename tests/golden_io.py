@@ -59,14 +59,14 @@ E2E_BERT = weights.BertConfig(hidden=768, layers=2, heads=12, mlp=512, vocab=512
 E2E_BS8_LENGTHS = (3, 11, 6, 4, 9, 5, 7, 11)
 
 
-def e2e_small_inputs(name="e2e_small", lengths=(3, 11, 6)):
+def e2e_small_inputs(name="e2e_small", lengths=(3, 11, 6), modality="intra_inter"):
     z = load(name + ".npz")
     vw, bw = weights.make_vit_weights(E2E_VIT, seed=11), weights.make_bert_weights(E2E_BERT, seed=12)
     b = synth.scientific_batch(bs=len(lengths), seed=31, lengths=list(lengths), dup_items=True, res=32, words=8, vocab=512,
                                item_num=40)
     assert sha(b.images) == str(z["images_sha"]) and np.array_equal(b.text.numpy(), z["text"])
     assert np.array_equal(b.ids.numpy(), z["ids"])
-    P = weights.make_trainable_params(seed=101, n_side=3)
+    P = weights.make_trainable_params(seed=101, n_side=3, modality=modality)
     return z, vw, bw, b, P
 
 

@@ -186,6 +186,47 @@ def test_uncached_end_to_end_matches_reference():
             assert (got - ref).norm() <= 0.15 * ref.norm() + 1e-7, f"grad {n} vs golden: {(got - ref).norm() / ref.norm():.2e}"
 
 
+def test_modality_inter_end_to_end_matches_reference():
+    """`--modality inter` (Code_Uncached/model/model.py:38-39,70-72,182-205): only the inter-modal tower has parameters,
+    `com_dense` is 64 -> 64.  Loss and the mm embeddings against the reference run with that flag (`e2e_inter.npz`, 1e-3: fp16
+    encoder operands), gradients against the oracle on the same HIP taps (tight) — the oracle itself is pinned to that
+    fixture at 5e-4 on the CPU.  The module tree carries exactly the reference's keys for this modality."""
+    z, vw, bw, b, P = gio.e2e_small_inputs("e2e_inter", modality="inter")
+    args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8, modality="inter")
+    model = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+    names = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert names == set(P), (sorted(names - set(P))[:4], sorted(set(P) - names)[:4])
+    helpers.load_trainables(model, P)
+    model.eval()
+    ids, lm = b.ids.cuda().view(-1), b.log_mask.cuda()
+    img, txt = b.images.cuda(), b.text.cuda()
+    _, (_, mm) = model.mm_encoder(img, txt)
+    real = (b.ids.view(-1) != 0)
+    ref = torch.from_numpy(z["mm"]).double()
+    rel = ((mm.cpu().double() - ref)[real].norm() / ref[real].norm()).item()
+    assert rel < 1e-3, f"mm: rel {rel:.3e}"
+    loss = model(ids, img, txt, lm, 0)
+    assert abs(loss.item() - float(z["loss"])) < 1e-3 * float(z["loss"]), (loss.item(), float(z["loss"]))
+    loss.backward()
+    tc = model.mm_encoder.cv_encoder.forward_taps(img, [0, 1, 2]).cpu()
+    tt = model.mm_encoder.bert_encoder.forward_taps(txt, [0, 1, 2]).cpu()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lo, _ = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, Pg, O.side_layer_list("0,1", False), modality="inter")
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 2e-5 * abs(lo.item())
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if Pg[n].grad is None:           # the two encoder heads are outside this modality's loss
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        g, go = p.grad.cpu().double(), Pg[n].grad.double()
+        tol = 1e-3 if "side_gate" in n else 3e-4          # a gate gradient is ONE scalar: a sum of cancelling <dF, tap_cv - tap_text> products
+        assert (g - go).norm() <= tol * go.norm() + 1e-7, f"grad {n} vs oracle on the same taps: {(g - go).norm() / go.norm():.2e}"
+    with pytest.raises(NotImplementedError):
+        helpers.build_model(helpers.make_args(modality="intra"), 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
+
+
 def test_uncached_end_to_end_gradients_on_eight_sequences_match_reference():
     """End-to-end gradients pinned to the REFERENCE (not the oracle) on the 8-sequence fixture (`e2e_bs8.npz`, produced
     by the imported `Code_Uncached` ModelMM): loss and item embeddings within 1e-3, the gradient of all trainable
@@ -762,6 +803,40 @@ def test_out_of_range_ids_are_loud_not_wild_reads():
     hist = torch.zeros(3, 4, dtype=torch.int32).cuda()
     ranks = ops.score_rank(prec[:3].contiguous(), item_emb, hist, torch.tensor([5, n + 7, 0], dtype=torch.int32).cuda()).cpu()
     assert ranks[0] >= 1 and ranks[1] == -1 and ranks[2] == -1
+
+
+def test_cached_step_on_a_poisoned_heap_is_finite_and_its_weight_gradients_reproducible(lib):
+    """The executor's workspace comes from torch's caching allocator uninitialised.  Regression: a split-K partial that no
+    workgroup wrote (an empty K range) was summed by the reducer — NaN gradients that depended on what the heap held before.
+    Here the heap is filled with NaN first; and since the weight-gradient products combine their split-K partials in a fixed
+    order (scratch + reducer instead of atomics), two backward passes give bit-identical adapter weight gradients."""
+    from iisan_amd import tapstore
+    n, bs = 2000, 1024
+    b = synth.scientific_batch(bs=bs, seed=41, item_num=n, res=2, words=2)
+    ids, lm = b.ids.view(-1).cuda(), b.log_mask.cuda()
+    args = helpers.make_args(drop_rate=0.0)
+    model = helpers.build_model(args, n, b.pop_prob, cached=True)
+    shapes = {k: tuple(p.shape) for k, p in model.named_parameters() if p.requires_grad}
+    helpers.load_trainables(model, weights.fill_params_seeded(shapes, seed=555))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    model.tap_stores = tuple(tapstore.TapStore(torch.randn(n + 1, 7, 768, generator=g, device="cuda") * 0.25, range(7), "cuda", "fp32")
+                             for _ in range(2))
+    model.train()
+    runs = []
+    for _ in range(2):
+        poison = torch.full((3 << 28,), float("nan"), device="cuda")       # 3 GiB of NaN back to the allocator's free lists
+        del poison
+        model.zero_grad(set_to_none=True)
+        loss = model(ids, None, None, lm, None)
+        loss.backward()
+        assert torch.isfinite(loss).item()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad}
+        for k, v in grads.items():
+            assert torch.isfinite(v).all().item(), k
+        runs.append(grads)
+    for k in runs[0]:
+        if "adapter_list" in k and k.endswith("weight"):
+            assert torch.equal(runs[0][k], runs[1][k]), k
 
 
 @pytest.mark.parametrize("route", ["x3", "sanb"])

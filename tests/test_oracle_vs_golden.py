@@ -95,6 +95,34 @@ def test_e2e_small_matches_reference(case):
         _close(gio.sample_like_golden(p.grad), z["g/" + n], 5e-4, 1e-7, f"grad {n}")
 
 
+def test_modality_inter_matches_reference():
+    """`--modality inter` (Code_Uncached/model/model.py:38-39,70-72,182-205): only the inter-modal tower exists and
+    `com_dense` is 64 -> 64 on its output.  Fixture `e2e_inter.npz` = the reference run with that flag; tensors outside
+    the loss (the two encoder heads) have no gradient there and none here."""
+    z, vw, bw, b, P = gio.e2e_small_inputs("e2e_inter", modality="inter")
+    assert P["com_dense.weight"].shape == (64, 64) and not any("cv_adapter" in k or "bert_adapter" in k or "fc_cv" in k for k in P)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    with torch.no_grad():
+        taps_cv = O.vit_cls_taps(b.images, vw, gio.E2E_VIT)
+        taps_tx = O.bert_cls_taps(b.text, bw, gio.E2E_BERT)
+    loss, aux = O.model_loss_from_taps(b.ids, taps_cv, taps_tx, b.log_mask, b.pop_prob, P, O.side_layer_list("0,1", False),
+                                       modality="inter")
+    assert aux["cv"] is None and aux["text"] is None
+    _close(aux["mm"].detach(), z["mm"], 2e-5, 2e-5, "mm")
+    _close(loss.detach(), z["loss"], 2e-5, 0, "loss")
+    loss.backward()
+    n_checked = 0
+    for n, p in P.items():
+        if "g/" + n in z.files:
+            _close(gio.sample_like_golden(p.grad), z["g/" + n], 5e-4, 1e-7, f"grad {n}")
+            n_checked += 1
+        else:
+            assert p.grad is None and ("classifier" in n or "title.fc" in n), n
+    assert n_checked == len(P) - 4
+    with pytest.raises(NotImplementedError):
+        O.model_loss_from_taps(b.ids, taps_cv, taps_tx, b.log_mask, b.pop_prob, P, O.side_layer_list("0,1", False), modality="intra")
+
+
 def test_eval_ranks_match_reference():
     z, seqs, tables, P = gio.eval_inputs()
     item_emb = torch.nn.functional.linear(torch.cat(tables, 1), P["com_dense.weight"], P["com_dense.bias"])
