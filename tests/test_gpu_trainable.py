@@ -449,6 +449,31 @@ def test_eval_model_reference_signature_and_log_lines():
                             int(z["item_num"]), log, "validation", 0)
 
 
+def test_eval_model_with_modality_inter_scores_on_the_inter_table_only():
+    """`metrics.py:175-178,192-199`: with `--modality inter` the item table is `com_dense(item_embeddings_inter)` and the
+    user sequences are built from it alone; the image / text tables the caller still passes are not read."""
+    from iisan_amd import evaluate
+    z, seqs, tables, P = gio.eval_inputs()
+    n = int(z["item_num"])
+    args = helpers.make_args(modality="inter")
+    model = helpers.build_model(args, n, torch.ones(n + 1), cached=True)
+    assert tuple(model.com_dense.weight.shape) == (64, 64)
+    helpers.load_trainables(model, {k: v for k, v in P.items() if k.startswith("user_encoder.")})
+    model.eval()
+
+    class Log:
+        lines = []
+        def info(self, msg): self.lines.append(msg)
+
+    item_emb = ops.LinearFn.apply(tables[2].cuda(), model.com_dense.weight, model.com_dense.bias).detach()
+    ranks = evaluate.evaluate_ranks(model, item_emb, seqs, [s[:-1] for s in seqs], max_seq_len=10, batch=16).cpu().long()
+    want_hit, _ = evaluate.hit_ndcg(ranks)
+    junk = torch.full_like(tables[0], float("nan"))
+    hit = evaluate.eval_model(model, {u: torch.tensor(s[:-1]) for u, s in enumerate(seqs)}, dict(enumerate(seqs)), junk, [junk, tables[2]],
+                              16, args, n, Log(), "validation", 0)
+    assert abs(hit - want_hit) < 1e-9
+
+
 def test_tap_cache_feeds_the_cached_path_identically():
     """Cached == Uncached given the cached taps (SURVEY.md §4 invariant 3): build_tap_cache -> CachedIISANAdaptedMModel
     reproduces the Uncached wrapper's embeddings bit for bit."""
