@@ -92,6 +92,7 @@ EXTRA_SIGNATURES = {
     "iisan_set_sanb_fused": (None, [i32]),
     "iisan_set_sanb_debug": (None, [i32]),
     "iisan_set_sanb_schedule": (None, [i32, i32]),
+    "iisan_set_ce_debug": (None, [i32]),
     "iisan_set_ce_fast": (None, [i32]),
     "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_set_gemm32_accum_scratch": (None, [i32]),

@@ -395,7 +395,7 @@ __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x
 template <int MODE, int RS1>
 __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict__ prec, const float* __restrict__ score,
                                                          const float* __restrict__ log_mask, CeBufs b, int bs, int S,
-                                                         float d_loss, float* __restrict__ dX) {
+                                                         float d_loss, float* __restrict__ dX, int dbg = 0) {
     static_assert(MODE == CE_FWD || MODE == CE_DPREC || MODE == CE_FUSED, "row-fixed passes only");
     __shared__ __attribute__((aligned(16))) float sY[4][16 * YLD];
     __shared__ float sRed[4][16][E + 4];
@@ -498,6 +498,7 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             const f4 yb = *(const f4*)(myY + j * YLD + 16 * g + 4 * v + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (dbg & 1) { z[0] += ya[e] * xb[4 * v + e]; continue; }       // ablation (timing only): no logits product
                 z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
                 z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[e], xb[4 * v + 4 + e], z1, 0, 0, 0);
             }
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
 #pragma unroll
                 for (int et = 0; et < 4; ++et) {
                     const float ya = myY[(4 * g + r) * YLD + 16 * et + j];
+                    if (dbg & 2) { dacc[et][0] += ya * dz[r]; continue; }         // ablation (timing only)
                     dacc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya, dz[r], dacc[et], 0, 0, 0);
                 }
         }
@@ -802,6 +804,7 @@ __global__ __launch_bounds__(256) void ce_colpass_kernel(const float* __restrict
 // 1 (default): one fused FWD + DPREC row pass (online softmax) and the cooperative column pass; 2: separate FWD and DPREC
 // row passes (round-2a form); 0: the generic kernel everywhere (test knob)
 int g_ce_fast = 1;
+int g_ce_dbg = 0;
 bool rowpass_ok(int64_t bs, int S) { return g_ce_fast && S >= 5 && S + 1 <= MAXS1 && bs * (int64_t)(S + 1) < (1ll << 31); }
 
 int check(int64_t bs, int S, int Ein) {
@@ -820,6 +823,7 @@ extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
 }
 
 extern "C" void iisan_set_ce_fast(int32_t on) { g_ce_fast = on; }
+extern "C" void iisan_set_ce_debug(int32_t bits) { g_ce_dbg = bits; }        // ablation bits of the fused row pass (timing only)
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,
@@ -841,7 +845,7 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_LAUNCH_OK();
     // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it
     if (rowpass_ok(bs, S) && g_ce_fast == 1 && S + 1 <= 11)
-        hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
+        hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr, g_ce_dbg);
     else if (rowpass_ok(bs, S) && g_ce_fast == 1)
         hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
     else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_FWD, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
