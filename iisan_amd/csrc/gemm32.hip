@@ -312,6 +312,29 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int 
     const Gemm32Prob& p = rb.p[blockIdx.z];
     const float* P = rb.P[blockIdx.z];
     const int64_t stride = rb.stride[blockIdx.z], total = p.M * p.N;
+    if (epi == 0 && !p.bias && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.resid || (p.ldr & 3) == 0)) {
+        // plain sum (+ old C): the weight-gradient reductions.  16-byte accesses, eight partials in flight per thread; the
+        // summation order is fixed (y ascending within each of the eight lanes of the unroll, lanes combined in order)
+        const int64_t total4 = total / 4;
+        const int n4 = p.N / 4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t m = i / n4;
+            const int n = (int)(i - m * n4) * 4;
+            f4 acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            int y = 0;
+            for (; y + 8 <= ks; y += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += *(const f4*)(P + (int64_t)(y + u) * stride + 4 * i);
+            }
+            for (int u = 0; y < ks; ++y, ++u) acc[u] += *(const f4*)(P + (int64_t)y * stride + 4 * i);
+            f4 v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            if (p.resid) v += *(const f4*)(p.resid + m * p.ldr + n);
+            *(f4*)(p.C + m * p.ldc + n) = v;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / p.N;
         const int n = (int)(i - m * p.N);
