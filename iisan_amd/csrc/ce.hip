@@ -498,7 +498,9 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             const f4 yb = *(const f4*)(myY + j * YLD + 16 * g + 4 * v + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+#ifdef CE_ABLATE      // build with -DCE_ABLATE for tools/ce_ablate.py: even the untaken branch costs the row pass 130 us (450 -> 585)
                 if (dbg & 1) { z[0] += ya[e] * xb[4 * v + e]; continue; }       // ablation (timing only): no logits product
+#endif
                 z = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[e], xb[4 * v + e], z, 0, 0, 0);
                 z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[e], xb[4 * v + 4 + e], z1, 0, 0, 0);
             }
@@ -555,7 +557,9 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
 #pragma unroll
                 for (int et = 0; et < 4; ++et) {
                     const float ya = myY[(4 * g + r) * YLD + 16 * et + j];
+#ifdef CE_ABLATE
                     if (dbg & 2) { dacc[et][0] += ya * dz[r]; continue; }         // ablation (timing only)
+#endif
                     dacc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya, dz[r], dacc[et], 0, 0, 0);
                 }
         }

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Ablation of the fused in-batch CE row pass at the Cached batch size (timing only: results are wrong with a bit set)."""
+"""Ablation of the fused in-batch CE row pass at the Cached batch size (timing only: results are wrong with a bit set).
+Needs a library built with -DCE_ABLATE (make -C iisan_amd/csrc EXTRA=-DCE_ABLATE); the product build compiles the
+ablation branches out — measured on MI355X: full 634 us per forward call, no logits MFMAs 520, no d_prec MFMAs 484, none 407."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
