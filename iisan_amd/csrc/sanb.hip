@@ -8,13 +8,14 @@
 // of sidenet.hip — the reference's `AdapterBlock.forward` and the gated fusion around it
 // (Code_Cached/model/modules.py:112-116, Code_Cached/model/model.py:320-341) and what autograd derives from them.
 // Measured before (Cached, bs = 1024, rocprofv3): 193 us forward / 444 us backward per step in 3 + 7 launches, each
-// streaming the [M, 768] state of every tower through HBM again; here a 32-row tile of the state stays in LDS between
+// streaming the [M, 768] state of every tower through HBM again; here a 16-row tile of the state stays in LDS between
 // the fusion and the two products.
 //
-// Arithmetic: exact fp32 on the f32-input matrix cores (v_mfma_f32_32x32x2_f32 = an fp32 FMA chain).  Bound: the f32
-// matrix rate (157 TF): 2·2·32·D·64 FLOP per tile and step.  One 512-thread workgroup per 32-row tile and tower; the
-// fused row tile [32, D] fp32 lives in LDS (D <= 1024), weights come straight from L2 as 16-byte fragments: a lane's
-// four consecutive k-values feed four MFMAs, with the same k-permutation applied to the other operand's LDS read.
+// Arithmetic: exact fp32 on the f32-input matrix cores (v_mfma_f32_16x16x4_f32 = an fp32 FMA chain).  2·2·16·D·64 FLOP per
+// tile and step: 12.3k matrix-pipe cycles per wave and tile, ~64 of the 150 us of a Cached launch; the rest is the streaming
+// of the tile (what was tried to overlap or shrink either part).  One 256-thread workgroup per 16-row tile and
+// tower, three per CU; the fused row tile [16, D] fp32 lives in LDS (D <= 1024), weights come straight from L2 as 16-byte
+// fragments: a lane's four consecutive k-values feed four MFMAs, with the same k-assignment on the other operand's LDS read.
 #include "common.h"
 
 namespace {
@@ -22,7 +23,7 @@ namespace {
 
 constexpr int R = 16;              // rows per tile
 constexpr int RD = 64;             // adapter bottleneck (cfg->down)
-constexpr int UST = RD + 2;        // LDS row stride of the [16, 64] buffer; stride % 32 == 2: conflict-free A-operand reads
+constexpr int UST = RD + 4;        // LDS row stride of the [16, 64] buffer: 16-byte aligned rows, 4 banks apart
 constexpr int NT = 256;            // threads per workgroup (4 waves), three workgroups per CU (LDS: 3 x 53.5 KB)
 
 __device__ __forceinline__ float gate_of(const float* theta) { return 1.0f / (1.0f + __expf(-theta[0] / 0.1f)); }
@@ -35,8 +36,8 @@ struct SanbTower {
     int64_t lda, ldb, ldp;
     const float* gate;
     int32_t D, type;
-    const float* Wd; const float* bd;        // fwd: fc_down^T [D, 64], [64]      bwd: fc_up   [D, 64]  (K-major for the narrow product)
-    const float* Wu; const float* bu;        // fwd: fc_up^T   [64, D], [D]       bwd: fc_down [64, D]  (K-major for the wide product)
+    const float* Wd; const float* bd;        // narrow product's weight [64, D] (K contiguous): fwd fc_down as stored, bwd fc_up^T ; bias [64]
+    const float* Wu; const float* bu;        // wide product's weight   [D, 64] (K contiguous): fwd fc_up as stored,   bwd fc_down^T ; bias [D]
     float* F; float* U; float* A; float* O;  // fwd outputs: [M,D] [M,64] [M,64] [M,D]
     // backward
     const float* dO; const float* Upre;      // [M,D] gradient wrt O ; saved pre-activation [M,64]
@@ -61,57 +62,66 @@ __device__ __forceinline__ void stagger(int units) {
     for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
 }
 
-// LDS: tile [16][D+2] | [16][66]
-__host__ __device__ constexpr int lds_floats(int D) { return R * (D + 2) + R * UST; }
+// LDS: tile [16][D+4] | [16][68]
+__host__ __device__ constexpr int lds_floats(int D) { return R * (D + 4) + R * UST; }
 
-// narrow product: returns this wave's 16 x 16 fragment (columns 16*wave ..) of  X[16, D] · B[D, 64],  X in LDS (row stride
-// FS), B K-major in global memory (row k = 64 contiguous floats: a quarter-wave reads one 64-byte segment per MFMA operand).
-// Full K per wave: no partial sums to combine, bit-reproducible.  Two accumulators break the 40-cycle dependent latency.
+// Both products read 16 bytes per lane and instruction on BOTH operands: lane (i = lane&15, kq = lane>>4) loads the four
+// consecutive k-values 16 s + 4 kq .. +3 of its row (LDS) / of its output feature's weight row (global, K contiguous) and
+// feeds them to four MFMAs — the hardware contracts lane group kq of one operand with lane group kq of the other, so any
+// k-assignment works as long as both sides use the same one.  (The first version read one float per lane and MFMA on each
+// side: 2 x 192 four-byte loads + their address arithmetic per product and wave; the product loops are sensitive to every
+// instruction between the MFMAs — tools/sanb_ablate.py.)
+//
+// narrow product: returns this wave's 16 x 16 fragment (features 16*wave ..) of  X[16, D] · W^T,  X in LDS (row stride FS),
+// W = [64, D] row-major in global memory (the weight as stored for the forward pass, its transpose for the backward one).
+// Full K per wave: no partial sums to combine, bit-reproducible.  Two accumulators break the dependent-MFMA latency.
 template <int D>
-__device__ __forceinline__ f4 narrow_product(const float* Xs, const float* __restrict__ B, int wave, int lane) {
-    constexpr int FS = D + 2, PD = 32;
-    const float* xp = Xs + (lane & 15) * FS + (lane >> 4);
-    const float* bp = B + (int64_t)(lane >> 4) * RD + wave * 16 + (lane & 15);
+__device__ __forceinline__ f4 narrow_product(const float* Xs, const float* __restrict__ W, int wave, int lane) {
+    constexpr int FS = D + 4, NS = D / 16, PD = 8;
+    const f4* xp = (const f4*)(Xs + (lane & 15) * FS + 4 * (lane >> 4));                       // step s: xp[4 s]
+    const f4* wp = (const f4*)(W + (int64_t)(wave * 16 + (lane & 15)) * D + 4 * (lane >> 4));  // step s: wp[4 s]
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    float b[PD];
+    f4 b[PD];
 #pragma unroll
-    for (int p = 0; p < PD; ++p) b[p] = bp[(int64_t)(4 * p) * RD];
-    for (int k0 = 0; k0 < D; k0 += 4 * PD) {
+    for (int p = 0; p < PD; ++p) b[p] = wp[4 * p];
+    static_assert(NS % PD == 0, "K steps");
+    for (int s0 = 0; s0 < NS; s0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
-            const float a = xp[k0 + 4 * p];
-            const float bb = b[p];
-            if (k0 + 4 * (p + PD) < D) b[p] = bp[(int64_t)(k0 + 4 * (p + PD)) * RD];
-            if (p & 1) acc1 = mfma16(a, bb, acc1);
-            else acc0 = mfma16(a, bb, acc0);
+            const f4 a = xp[4 * (s0 + p)];
+            const f4 bb = b[p];
+            if (s0 + p + PD < NS) b[p] = wp[4 * (s0 + p + PD)];
+            acc0 = mfma16(a[0], bb[0], acc0);
+            acc1 = mfma16(a[1], bb[1], acc1);
+            acc0 = mfma16(a[2], bb[2], acc0);
+            acc1 = mfma16(a[3], bb[3], acc1);
         }
     }
     return acc0 + acc1;
 }
 
-// wide product in place:  T[16, D] += X[16, 64] · B[64, D]  (+ bias), T in LDS (row stride D+2), X in LDS (stride UST), B K-major
-// (row k = D contiguous floats).  A wave owns D/4 columns; fragments go in pairs (independent accumulators).
+// wide product in place:  T[16, D] += X[16, 64] · W^T  (+ bias), T in LDS (row stride D+4), X in LDS (stride UST), W = [D, 64]
+// row-major in global memory.  A wave owns D/4 features; fragments go in pairs (independent accumulators).
 template <int D>
-__device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const float* __restrict__ B, const float* __restrict__ bias,
+__device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const float* __restrict__ W, const float* __restrict__ bias,
                                              int wave, int lane) {
-    constexpr int FS = D + 2;
-    float a[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) a[s] = Xs[(lane & 15) * UST + 4 * s + (lane >> 4)];
+    constexpr int FS = D + 4;
     const int col = lane & 15, rg = lane >> 4;
-    const float* bp = B + (int64_t)rg * D + wave * (D / 4) + col;
-    float b0[16], b1[16];
+    f4 a[4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { b0[s] = bp[(int64_t)(4 * s) * D]; b1[s] = bp[(int64_t)(4 * s) * D + 16]; }
+    for (int s = 0; s < 4; ++s) a[s] = *(const f4*)(Xs + col * UST + 16 * s + 4 * rg);
+    const f4* wp = (const f4*)(W + (int64_t)(wave * (D / 4) + col) * RD + 4 * rg);      // feature n, step s: wp[n * 16 + 4 s]
+    f4 b0[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { b0[s] = wp[4 * s]; b1[s] = wp[16 * 16 + 4 * s]; }
 #pragma unroll 1
     for (int n0 = wave * (D / 4); n0 < (wave + 1) * (D / 4); n0 += 32) {
-        // the next pair's weights are requested before this pair's MFMAs: an L2 round trip (~1 us under load) per pair
-        // was otherwise exposed six times per tile
-        float nb0[16], nb1[16];
+        // the next pair's weights are requested before this pair's MFMAs
+        f4 nb0[4], nb1[4];
         const bool more = n0 + 32 < (wave + 1) * (D / 4);
         if (more) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) { nb0[s] = bp[(int64_t)(4 * s) * D + 32]; nb1[s] = bp[(int64_t)(4 * s) * D + 48]; }
+            for (int s = 0; s < 4; ++s) { nb0[s] = wp[32 * 16 + 4 * s]; nb1[s] = wp[48 * 16 + 4 * s]; }
         }
         f4 c0, c1;
         float* t0 = Ts + (4 * rg) * FS + n0 + col;
@@ -119,14 +129,16 @@ __device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const f
 #pragma unroll
         for (int r = 0; r < 4; ++r) { c0[r] = t0[r * FS] + bi0; c1[r] = t0[r * FS + 16] + bi1; }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { c0 = mfma16(a[s], b0[s], c0); c1 = mfma16(a[s], b1[s], c1); }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c0 = mfma16(a[s][e], b0[s][e], c0); c1 = mfma16(a[s][e], b1[s][e], c1); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t0[r * FS] = c0[r]; t0[r * FS + 16] = c1[r]; }
         if (more) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) { b0[s] = nb0[s]; b1[s] = nb1[s]; }
+            for (int s = 0; s < 4; ++s) { b0[s] = nb0[s]; b1[s] = nb1[s]; }
         }
-        bp += 32;
+        wp += 32 * 16;
     }
 }
 
@@ -134,8 +146,8 @@ template <int D>
 __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SanbTower& t = args.t[blockIdx.y];
-    constexpr int FS = D + 2, d4 = D / 4;
-    float* Fs = smem;                 // [16][D + 2]   F, then O in place
+    constexpr int FS = D + 4, d4 = D / 4;
+    float* Fs = smem;                 // [16][D + 4]   F, then O in place
     float* As = smem + R * FS;        // [16][66]      act(U)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool gated = t.gate != nullptr;
@@ -215,14 +227,14 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     }
 }
 
-// backward of one step.  t.Wd = fc_up [D, 64] (K-major for dA = dO · Wu), t.Wu = fc_down [64, D] (K-major for dU · Wd)
+// backward of one step.  t.Wd = fc_up^T [64, D] (dA = dO · fc_up), t.Wu = fc_down^T [D, 64] (dU · fc_down): contraction index contiguous
 template <int D>
 __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4];
     const SanbTower& t = args.t[blockIdx.y];
-    constexpr int FS = D + 2, d4 = D / 4;
-    float* Gs = smem;                 // [16][D + 2]  dO, then dF in place
+    constexpr int FS = D + 4, d4 = D / 4;
+    float* Gs = smem;                 // [16][D + 4]  dO, then dF in place
     float* Ds = smem + R * FS;        // [16][66]     dU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool gated = t.gate != nullptr;

@@ -200,7 +200,7 @@ struct SideBufs {
     float* dU[3];                    // [M, down]
     float* dDP;                      // [M, d]
     void* x3; size_t x3_bytes;       // scratch of the split-operand GEMM (operand images + scales), null = not used
-    float* WT[3][2];                 // backward of the fused SANB step: Wu^T [64, D] and Wd^T [D, 64] of the current step
+    float* WT[3][2];                 // backward of the fused SANB step: fc_down^T [D, 64] and fc_up^T [64, D] of the current step
     float* skws; size_t skws_floats; // split-K scratch of the skinny long-K products (gemm32_set_scratch)
 };
 
@@ -422,16 +422,13 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
         }
         if (step_fusable(p, sm)) {            // fusion + down + activation + up of every active tower in one launch
             SanbTowerDesc td[3];
-            const float* tin[6]; float* tout[6]; int32_t trows[6], tcols[6];
             for (int a = 0; a < sm.nact; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
-                tin[2 * a] = c.W(p.wd(z, k)); tout[2 * a] = b.WT[z][0]; trows[2 * a] = p.r; tcols[2 * a] = p.D[z];              // fc_down [64,D] -> [D,64]
-                tin[2 * a + 1] = c.W(p.wd(z, k) + 2); tout[2 * a + 1] = b.WT[z][1]; trows[2 * a + 1] = p.D[z]; tcols[2 * a + 1] = p.r;  // fc_up [D,64] -> [64,D]
                 tower_desc(td[a], c, z, k, sm);
-                td[a].Wd = b.WT[z][0]; td[a].bd = c.W(p.wd(z, k) + 1); td[a].Wu = b.WT[z][1]; td[a].bu = c.W(p.wd(z, k) + 3);
+                // both weights as stored: fc_down [64, D] and fc_up [D, 64] have the contraction index contiguous
+                td[a].Wd = c.W(p.wd(z, k)); td[a].bd = c.W(p.wd(z, k) + 1); td[a].Wu = c.W(p.wd(z, k) + 2); td[a].bu = c.W(p.wd(z, k) + 3);
                 td[a].F = b.F[k][z]; td[a].U = b.U[k][z]; td[a].A = b.A[k][z]; td[a].O = b.O[k][z];
             }
-            IISAN_TRY(launch_sanb_transpose(tin, tout, trows, tcols, 2 * sm.nact, s));
             IISAN_TRY(launch_sanb_fwd(td, sm.nact, M, cfg->gelu, s));
             continue;
         }
@@ -507,15 +504,19 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
             }
             IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));
             SanbTowerDesc td[3];
+            const float* tin[6]; float* tout[6]; int32_t trows[6], tcols[6];
             for (int a = 0; a < na; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
+                tin[2 * a] = c.W(p.wd(z, k)); tout[2 * a] = b.WT[z][0]; trows[2 * a] = p.r; tcols[2 * a] = p.D[z];              // fc_down [64,D] -> [D,64]
+                tin[2 * a + 1] = c.W(p.wd(z, k) + 2); tout[2 * a + 1] = b.WT[z][1]; trows[2 * a + 1] = p.D[z]; tcols[2 * a + 1] = p.r;  // fc_up [D,64] -> [64,D]
                 tower_desc(td[a], c, z, k, sm);
-                td[a].Wd = c.W(p.wd(z, k) + 2); td[a].Wu = c.W(p.wd(z, k));      // fc_up [D,64] and fc_down [64,D] as stored: K-major for the backward products
+                td[a].Wd = b.WT[z][1]; td[a].Wu = b.WT[z][0];      // dA = dO · fc_up: fc_up^T [64, D];  dU · fc_down: fc_down^T [D, 64] (contraction index contiguous)
                 td[a].dO = b.dO[z]; td[a].Upre = b.U[k][z]; td[a].dU = b.dU[z];
                 td[a].dprev = k > 0 ? b.dO[z] : nullptr;     // block 0 starts from zeros / a tap: nobody reads that gradient
                 td[a].dgate = cfg->gated ? G(p.gate(z, k)) : nullptr;
                 td[a].dbu = G(p.wd(z, k) + 3); td[a].dbd = G(p.wd(z, k) + 1);
             }
+            IISAN_TRY(launch_sanb_transpose(tin, tout, trows, tcols, 2 * na, s));
             IISAN_TRY(launch_sanb_bwd(td, na, M, cfg->gelu, s));
             for (int a = 0; a < na; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
