@@ -35,7 +35,21 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     __shared__ float red[4];
     const int64_t c4 = cols / 4, total = rows * c4;
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four loads in flight per thread (one per iteration left the pass latency-bound: 12.6 us for 35 MB)
+    for (; i + 3 * stride < total; i += 4 * stride) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = i + u * stride, r = q / c4, c = (q - r * c4) * 4;
+            v[u] = *(const f4*)(x + r * ld + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+    }
+    for (; i < total; i += stride) {
         const int64_t r = i / c4, c = (i - r * c4) * 4;
         const f4 v = *(const f4*)(x + r * ld + c);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
