@@ -85,16 +85,22 @@ __device__ __forceinline__ f4 narrow_product(const float* Xs, const float* __res
 #pragma unroll
     for (int p = 0; p < PD; ++p) b[p] = wp[4 * p];
     static_assert(NS % PD == 0, "K steps");
+    // The ring only exists if the scheduler is fenced: unfenced, hipcc sinks every weight load to one or two steps before its
+    // use (register pressure heuristics) and each step waits a whole L2 round trip — s_waitcnt vmcnt(0..1) before every group
+    // of four MFMAs in the ISA, the matrix pipe 30 % busy and the waves 52 % of their time parked (rocprofv3 PMC).
+    __builtin_amdgcn_sched_barrier(0);
     for (int s0 = 0; s0 < NS; s0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
             const f4 a = xp[4 * (s0 + p)];
             const f4 bb = b[p];
             if (s0 + p + PD < NS) b[p] = wp[4 * (s0 + p + PD)];
+            __builtin_amdgcn_sched_barrier(0);
             acc0 = mfma16(a[0], bb[0], acc0);
             acc1 = mfma16(a[1], bb[1], acc1);
             acc0 = mfma16(a[2], bb[2], acc0);
             acc1 = mfma16(a[3], bb[3], acc1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     return acc0 + acc1;
@@ -123,6 +129,7 @@ __device__ __forceinline__ void wide_product(float* Ts, const float* Xs, const f
 #pragma unroll
             for (int s = 0; s < 4; ++s) { nb0[s] = wp[32 * 16 + 4 * s]; nb1[s] = wp[48 * 16 + 4 * s]; }
         }
+        __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs (see narrow_product)
         f4 c0, c1;
         float* t0 = Ts + (4 * rg) * FS + n0 + col;
         const float bi0 = bias ? bias[n0 + col] : 0.f, bi1 = bias ? bias[n0 + 16 + col] : 0.f;

@@ -913,7 +913,9 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
     for k in g0:
         scale = g0[k].abs().max().item() + 1e-20
         err = (g1[k] - g0[k]).abs().max().item() / scale
-        assert err < (2e-3 if "user_encoder" in k else 5e-4), (k, err)
+        # (a gate gradient is ONE scalar, the sum of 8.6 M cancelling <dF, tap - state> products: its summation tree differs
+        #  between the routes and, through the atomics, between runs — seen at 7e-4)
+        assert err < (2e-3 if ("user_encoder" in k or "side_gate" in k) else 5e-4), (k, err)
         differ += int(not torch.equal(g0[k], g1[k]))
     if not (versa and route == "sanb"):      # Versa's towers have different widths: no fused step there (yet)
         assert differ > 0                    # the two routes really are different kernels
