@@ -449,21 +449,19 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
     // the top of the iteration every tile waited for an L2 round trip (FWD 303 us against 110 us of MFMA time)
     f4 yreg[4];
     int mreg[3] = {0, 0, 0};
+    // Branch-free: a tile index past the end re-reads the last tile, a row past NY re-reads row NY-1 (finite values that
+    // meet dz = 0) — every conditional load was a saveexec / branch pair in the loop, and a join makes the waitcnt pass drain.
     auto prefetch = [&](int yt_) {
-        const int y0_ = yt_ * 16;
+        const int y0_ = (yt_ < ntiles ? yt_ : ntiles - 1) * 16;
         const int r = lane >> 2, ch = lane & 3;
-        const int yr = y0_ + r;
+        const int yr = y0_ + r < NY ? y0_ + r : NY - 1;
+        const float* yp = Y + (int64_t)yr * E + ch * 16;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            yreg[v] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (yt_ < ntiles && yr < NY) yreg[v] = *(const f4*)(Y + (int64_t)yr * E + ch * 16 + v * 4);
-        }
-        if (lane < 16 && yt_ < ntiles) {
-            const int cc = y0_ + lane < NY ? y0_ + lane : NY - 1;
-            mreg[0] = b.ids32[cc];
-            mreg[1] = b.colpad[cc];
-            mreg[2] = __float_as_int(b.debias[cc]);
-        }
+        for (int v = 0; v < 4; ++v) yreg[v] = *(const f4*)(yp + v * 4);
+        const int cc = y0_ + (lane & 15) < NY ? y0_ + (lane & 15) : NY - 1;
+        mreg[0] = b.ids32[cc];
+        mreg[1] = b.colpad[cc];
+        mreg[2] = __float_as_int(b.debias[cc]);
     };
     prefetch(wave);
     for (int yt = wave; yt < ntiles; yt += 4) {
@@ -506,6 +504,17 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             }
         }
         z += z1;
+        // the second product's 16 transposed tile reads are requested NOW, fenced, and land behind the mask / exp arithmetic:
+        // left to the compiler each pair sat right in front of its two MFMAs behind an lgkmcnt(0) (eight exposed LDS
+        // round trips per tile)
+        float yt16[4][4];
+        if (MODE != CE_FWD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int et = 0; et < 4; ++et) yt16[r][et] = myY[(4 * g + r) * YLD + 16 * et + j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const bool whole = y0 + 16 <= NY;            // wave-uniform
         const int lab_r = row_label - (y0 + 4 * g);  // r with column == label, if in 0..3
         float dz[4], fv[4];
@@ -556,11 +565,10 @@ __global__ __launch_bounds__(256) void ce_rowpass_kernel(const float* __restrict
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int et = 0; et < 4; ++et) {
-                    const float ya = myY[(4 * g + r) * YLD + 16 * et + j];
 #ifdef CE_ABLATE
-                    if (dbg & 2) { dacc[et][0] += ya * dz[r]; continue; }         // ablation (timing only)
+                    if (dbg & 2) { dacc[et][0] += yt16[r][et] * dz[r]; continue; }         // ablation (timing only)
 #endif
-                    dacc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya, dz[r], dacc[et], 0, 0, 0);
+                    dacc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(yt16[r][et], dz[r], dacc[et], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_wave_barrier();
