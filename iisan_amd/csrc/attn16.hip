@@ -17,6 +17,9 @@
 //   * fp32 softmax statistics; masked keys (BERT attention_mask == 0) take the constant fp32-min score exactly like
 //     HF's additive mask, so an all-masked padding item attends uniformly; structural pad keys get -inf.
 #include "common.h"
+#ifndef ATTN_KBATCH
+#define ATTN_KBATCH 4
+#endif
 
 static int g_attn_dbg = 0;
 extern "C" void iisan_set_attn_debug(int v) { g_attn_dbg = v; }
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             // the wave time in waits).
             f4 sc[NT16];
             {
-                constexpr int KBATCH = NT16 >= 13 ? 7 : (NT16 % 4 == 0 ? 4 : NT16);        // tiles whose K fragments are requested together (13 = 7 + 6)
+                constexpr int KBATCH = NT16 >= 13 ? ATTN_KBATCH : (NT16 % 4 == 0 ? 4 : NT16);        // tiles whose K fragments are requested together
 #pragma unroll
                 for (int t0 = 0; t0 < NT16; t0 += KBATCH) {
                     V8 kf[KBATCH][2];
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
                             if (t0 + u < NT16) kf[u][kk] = *(const V8*)(sK + ((t0 + u) * 16 + j) * 128 + (((kk * 4 + g) ^ (j & 7)) << 4));
+                    __builtin_amdgcn_sched_barrier(0);      // unfenced, hipcc sinks the reads back to one or two MFMAs before their use
 #pragma unroll
                     for (int u = 0; u < KBATCH; ++u) {
                         if (t0 + u >= NT16) continue;
