@@ -9,12 +9,17 @@ namespace {
 // v = x + delta16 (delta optional: the 16-bit output of the preceding O / FC2 GEMM, so the fp32 read-modify-write of
 // the residual stream happens HERE, in an HBM-bound kernel, instead of stalling the MFMA pipeline in a GEMM epilogue);
 // sum32 <- v (optional, may alias x); out32 / out16 <- LN(v) (optional, out32 may alias x).  g == nullptr: add only.
-template <typename T>
+// Which optional operands exist is COMPILE TIME (V bit 0: delta, 1: delta2, 2: sum32, 3: LayerNorm outputs): with run-time
+// null tests every load sat behind its own branch and hipcc waited for each one before issuing the next — one load in flight
+// per wave, six HBM round trips per row (ISA: load, s_waitcnt vmcnt(0), load, s_waitcnt vmcnt(0), ...).  Now all loads of a
+// row are requested first.
+template <typename T, int V>
 __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const typename T::elem* __restrict__ delta,
                                                            const typename T::elem* __restrict__ delta2,
                                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                            float* sum32, typename T::elem* __restrict__ out16,
                                                            float* out32, int64_t rows) {
+    constexpr bool D1 = V & 1, D2 = (V & 2) != 0, SUM = (V & 4) != 0, LN = (V & 8) != 0;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -22,24 +27,33 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
     // accesses (measured: 220.7 -> 201.8 us average per launch over a step's 49 launches)
     const float* xr = x + row * 768;
     f4 v[3];
-    float s = 0.f;
+    typename T::v4 d1[3], d2[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         v[i] = __builtin_nontemporal_load((const f4*)(xr + i * 256 + lane * 4));
-        if (delta) {
-            const typename T::v4 d = __builtin_nontemporal_load((const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4));
+        if (D1) d1[i] = __builtin_nontemporal_load((const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4));
+        if (D2) d2[i] = __builtin_nontemporal_load((const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4));
+    }
+    f4 gg[3], bb[3];
+    if (LN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
-        }
-        if (delta2) {       // added AFTER delta, in fp32: (x + delta) + delta2 — the same value as two passes produce
-            const typename T::v4 d = __builtin_nontemporal_load((const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4));
+        for (int i = 0; i < 3; ++i) { gg[i] = *(const f4*)(g + i * 256 + lane * 4); bb[i] = *(const f4*)(b + i * 256 + lane * 4); }
+    }
+    float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d[e]);
+    for (int i = 0; i < 3; ++i) {
+        if (D1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d1[i][e]);
         }
-        if (sum32) __builtin_nontemporal_store(v[i], (f4*)(sum32 + row * 768 + i * 256 + lane * 4));
+        if (D2) {       // added AFTER delta, in fp32: (x + delta) + delta2 — the same value as two passes produce
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d2[i][e]);
+        }
+        if (SUM) __builtin_nontemporal_store(v[i], (f4*)(sum32 + row * 768 + i * 256 + lane * 4));
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    if (!g) return;
+    if (!LN) return;
     const float mean = wave_sum(s) * (1.0f / 768.0f);
     float q = 0.f;
 #pragma unroll
@@ -53,10 +67,9 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = i * 256 + lane * 4;
-        const f4 gg = *(const f4*)(g + c), bb = *(const f4*)(b + c);
         f4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
         if (out32) *(f4*)(out32 + row * 768 + c) = y;
         if (out16) {
             typename T::v4 o;
@@ -204,10 +217,19 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
                              const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
     if (rows <= 0) return IISAN_OK;
     dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
-    if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(layernorm768_kernel<BF16>, grid, block, 0, s, x, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, sum32, (__bf16*)out16, out32, rows);
-    else
-        hipLaunchKernelGGL(layernorm768_kernel<F16>, grid, block, 0, s, x, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, sum32, (_Float16*)out16, out32, rows);
+    const int v = (delta16 ? 1 : 0) | (delta16b ? 2 : 0) | (sum32 ? 4 : 0) | (g ? 8 : 0);
+#define LN768_CASE(V)                                                                                                          \
+    case V:                                                                                                                    \
+        if (dtype16 == IISAN_BF16)                                                                                             \
+            hipLaunchKernelGGL((layernorm768_kernel<BF16, V>), grid, block, 0, s, x, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, sum32, (__bf16*)out16, out32, rows); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((layernorm768_kernel<F16, V>), grid, block, 0, s, x, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, sum32, (_Float16*)out16, out32, rows); \
+        break
+    switch (v) {
+        LN768_CASE(0); LN768_CASE(1); LN768_CASE(2); LN768_CASE(3); LN768_CASE(4); LN768_CASE(5); LN768_CASE(6); LN768_CASE(7);
+        LN768_CASE(8); LN768_CASE(9); LN768_CASE(10); LN768_CASE(11); LN768_CASE(12); LN768_CASE(13); LN768_CASE(14); LN768_CASE(15);
+    }
+#undef LN768_CASE
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
