@@ -147,14 +147,23 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     const float* pb = TB ? p.B + (kbeg + tid / TPRB) * p.ldb + n0 + (tid % TPRB) * 4 : p.B + (int64_t)(n0 + (tid >> 4)) * p.ldb + kbeg + (tid & 15) * 4;
     const int64_t sia = TA ? (int64_t)(256 / TPRA) * p.lda : (int64_t)16 * p.lda, sib = TB ? (int64_t)(256 / TPRB) * p.ldb : (int64_t)16 * p.ldb;
     const int64_t ska = TA ? (int64_t)TK * p.lda : TK, skb = TB ? (int64_t)TK * p.ldb : TK;
+    const int64_t last_t = (kend - kbeg - 1) / TK;
     auto fetch = [&](int slot, int64_t k) {
+        if constexpr (FAST) {
+            // Unconditional: a K-tile past the end re-reads the last one (never staged).  Behind `if (k < kend)` every load
+            // was a conditional one, the waitcnt pass lost count at the joins and drained the whole ring before each
+            // stage (s_waitcnt vmcnt(7..0) in front of the stage's eight LDS writes although 16 younger loads were in
+            // flight): the 3-deep ring worked as a 1-deep one.
+            int64_t t = (k - kbeg) / TK;
+            t = t < last_t ? t : last_t;
+#pragma unroll
+            for (int i = 0; i < TM / 16; ++i) ra[slot][i] = *(const f4*)(pa + t * ska + i * sia);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[slot][i] = *(const f4*)(pb + t * skb + i * sib);
+            return;
+        }
         if (k < kend) {
             if constexpr (FAST) {
-                const int64_t t = (k - kbeg) / TK;
-#pragma unroll
-                for (int i = 0; i < TM / 16; ++i) ra[slot][i] = *(const f4*)(pa + t * ska + i * sia);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rb[slot][i] = *(const f4*)(pb + t * skb + i * sib);
             } else {
                 load_tile<TM>(ra[slot], p.A, p.lda, TA, m0, p.M, k, kend, tid);
                 load_tile<TN>(rb[slot], p.B, p.ldb, TB, n0, p.N, k, kend, tid);
@@ -299,8 +308,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
     int64_t r1 = r0 + rows_per_block;
     if (r1 > b.M[z]) r1 = b.M[z];
     float s = 0.f;
-    if (n < b.N[z])
-        for (int64_t r = r0 + rl; r < r1; r += 4) s += b.X[z][r * b.ld[z] + n];
+    if (n < b.N[z]) {
+        // eight loads in flight per thread (one per iteration — what the plain loop compiles to — left each launch
+        // latency-bound: 19 us for a 35 MB operand); fixed order: partial sums of the eight lanes combined at the end
+        const float* xp = b.X[z] + n;
+        const int64_t ld = b.ld[z];
+        float part8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int64_t r = r0 + rl;
+        for (; r + 28 < r1; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part8[u] += xp[(r + 4 * u) * ld];
+        }
+        for (; r < r1; r += 4) s += xp[r * ld];
+        s += ((part8[0] + part8[1]) + (part8[2] + part8[3])) + ((part8[4] + part8[5]) + (part8[6] + part8[7]));
+    }
     part[rl][c] = s;
     __syncthreads();
     if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
