@@ -200,9 +200,36 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                                 acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
                     }
                 };
-                if (ksteps == TK / 4) {        // full tile: unrolled, so the LDS reads of later slices overlap the MFMAs of earlier ones
+                if (ksteps == TK / 4) {
+                    // full tile: the fragments of k-slice s+1 are read before the MFMAs of slice s, fenced — left alone hipcc
+                    // puts each slice's reads directly in front of its MFMAs behind an lgkmcnt(0) (the LDS latency exposed
+                    // TK/4 times per tile); reading the whole tile's fragments up front costs 60 registers and a wave of occupancy
+                    float ac[FM], bc[FN];
+                    auto frag = [&](int ks, float (&a)[FM], float (&b)[FN]) {
 #pragma unroll
-                    for (int ks0 = 0; ks0 < TK / 4; ks0 += KA) kstep(ks0);
+                        for (int f = 0; f < FM; ++f)
+                            a[f] = TA ? As_[(ks * 4 + fk) * ldt(TM) + wm * 16 * FM + f * 16 + fi] : As_[(wm * 16 * FM + f * 16 + fi) * LD + ks * 4 + fk];
+#pragma unroll
+                        for (int f = 0; f < FN; ++f)
+                            b[f] = TB ? Bs_[(ks * 4 + fk) * ldt(TN) + wn * 16 * FN + f * 16 + fi] : Bs_[(wn * 16 * FN + f * 16 + fi) * LD + ks * 4 + fk];
+                    };
+                    frag(0, ac, bc);
+#pragma unroll
+                    for (int ks = 0; ks < TK / 4; ++ks) {
+                        float an[FM], bn[FN];
+                        frag(ks + 1 < TK / 4 ? ks + 1 : ks, an, bn);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mf = 0; mf < FM; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < FN; ++nf)
+                                acc[ks % KA][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mf], bc[nf], acc[ks % KA][mf][nf], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int f = 0; f < FM; ++f) ac[f] = an[f];
+#pragma unroll
+                        for (int f = 0; f < FN; ++f) bc[f] = bn[f];
+                    }
                 } else {
                     for (int ks0 = 0; ks0 < ksteps; ks0 += KA) kstep(ks0);
                 }
