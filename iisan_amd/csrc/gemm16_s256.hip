@@ -253,6 +253,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
             qk_item = m0 / qk_S;
             qk_tok = m0 - qk_item * qk_S;
         }
+        // the lane's 32 bias values (its columns are the same for every 32-row block) are read from LDS ONCE per epilogue
+        // half, up front — read inside the block loop, each block's four reads sat right before their adds behind an
+        // lgkmcnt(0) (ISA): eight exposed LDS round trips per epilogue half
+        f4 bbv[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                bbv[ni][q4] = p.bias ? *(const f4*)(sBias + tn * SBN + wq * 64 + ni * 32 + 16 * fh + 4 * q4) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             if ((mi >> 1) != half) continue;
@@ -264,14 +273,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
                 if (m >= p.M || (p.debug & 1)) continue;
-                if (p.bias) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f4 bb = *(const f4*)(sBias + n + 4 * q4);
+                for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += bb[e];
-                    }
-                }
+                    for (int e = 0; e < 4; ++e) v[4 * q4 + e] += bbv[ni][q4][e];
                 typename T::elem* op;
                 if constexpr (EPI == EPI_QKVH16) {
                     op = (typename T::elem*)p.out + ((((int64_t)qk_item * p.qkv_heads + qk_hd) * 3 + qk_which) * qk_S + qk_tok) * 64 + (ni * 32 + 16 * fh);
