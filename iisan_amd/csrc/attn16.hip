@@ -323,21 +323,33 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::el
         for (int e = 0; e < 8; ++e) q[e] = T::to_f32(t[e]);
     }
     float mx = -INFINITY;
-    for (int k0 = 0; k0 < S; k0 += 8) {
-        const int key = k0 + kr;
-        float a = 0.f;
-        if (key < S) {
-            const V8 t = *(const V8*)(kb_ + (int64_t)key * 64 + kc * 8);
+    // five K rows (and their mask values) per lane in flight: one load per iteration behind an `if` — what the plain loop
+    // compiles to — made every one of the 25 iterations wait a whole memory round trip.  Keys past S re-read key S-1.
+    constexpr int KB = 5;
+    for (int k0 = 0; k0 < S; k0 += 8 * KB) {
+        V8 t[KB];
+        float kbv[KB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(q[e], T::to_f32(t[e]), a);
+        for (int u = 0; u < KB; ++u) {
+            const int key = k0 + 8 * u + kr;
+            const int kcl = key < S ? key : S - 1;
+            t[u] = *(const V8*)(kb_ + (int64_t)kcl * 64 + kc * 8);
+            kbv[u] = key_bias ? key_bias[item * S + kcl] : 0.f;
         }
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        a += __shfl_xor(a, 4, 64);
-        if (key >= S) a = -INFINITY;
-        else if (key_bias && key_bias[item * S + key] < 0.f) a = MASK_RAW;
-        if (kc == 0 && key < 256) sP[wave][key] = a;
-        mx = fmaxf(mx, a);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int key = k0 + 8 * u + kr;
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(q[e], T::to_f32(t[u][e]), a);
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (key >= S) a = -INFINITY;
+            else if (kbv[u] < 0.f) a = MASK_RAW;
+            if (kc == 0 && key < 256) sP[wave][key] = a;
+            mx = fmaxf(mx, a);
+        }
     }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -358,11 +370,21 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const typename T::el
     __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's sP writes (each wave reads only its own row)
     const int kg = lane >> 4, dq = lane & 15;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int key = kg; key < S; key += 4) {
-        const V4 v = *(const V4*)(vb_ + (int64_t)key * 64 + dq * 4);
-        const float p = sP[wave][key];
+    constexpr int VB = 8;                      // V rows per lane in flight (same reason as the K rows above)
+    for (int k0 = kg; k0 < S; k0 += 4 * VB) {
+        V4 v[VB];
+        float pr[VB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, T::to_f32(v[e]), acc[e]);
+        for (int u = 0; u < VB; ++u) {
+            const int key = k0 + 4 * u;
+            const int kcl = key < S ? key : S - 1;
+            v[u] = *(const V4*)(vb_ + (int64_t)kcl * 64 + dq * 4);
+            pr[u] = key < S ? sP[wave][kcl] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < VB; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(pr[u], T::to_f32(v[u][e]), acc[e]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
