@@ -273,19 +273,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_s256_kernel(Gemm16Args p, int t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
                 if (m >= p.M || (p.debug & 1)) continue;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q4 + e] += bbv[ni][q4][e];
+
                 typename T::elem* op;
                 if constexpr (EPI == EPI_QKVH16) {
                     op = (typename T::elem*)p.out + ((((int64_t)qk_item * p.qkv_heads + qk_hd) * 3 + qk_which) * qk_S + qk_tok) * 64 + (ni * 32 + 16 * fh);
                 } else {
                     op = (typename T::elem*)p.out + m * p.ldo + n;
                 }
-                f2 g[8];
+                f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) g[k] = (f2){v[2 * k], v[2 * k + 1]};
+                for (int k = 0; k < 8; ++k) g[k] = (f2){v[2 * k], v[2 * k + 1]} + (f2){bbv[ni][k >> 1][2 * (k & 1)], bbv[ni][k >> 1][2 * (k & 1) + 1]};
                 if constexpr (EPI == EPI_GELU16) gelu_erf_fast2x8(g);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
