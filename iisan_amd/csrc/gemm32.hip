@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_tile(float* S, const f4 (&v)[ROWS / 16], b
 // aligned (checked on the host): the fetch is then one pointer per operand, advanced per K-tile, and unconditional
 // 16-byte loads — the generic fetch spends ~160 VALU + 80 SALU instructions per K-tile on indices, bounds and alignment
 // (PMC), beside 64 MFMAs.
-template <int FLAGS, int TMV, bool FAST>
+template <int FLAGS, int TMV, bool FAST, int DEPTHV = 2>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi) {
     constexpr int TM = TMV;
     constexpr int WM = TMV >= 32 ? 2 : 1, WN = 4 / WM, FM = TMV / 16 / WM, FN = 4 / WN;
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
     // Three K-tiles in flight (register ring, statically indexed by unrolling x3): the products are tiny (one K-tile is
     // 64 MFMAs, ~0.3 us) and an HBM/L2 round trip is 1-2 us, so with one tile of look-ahead every iteration still
     // waited for most of a round trip.
-    constexpr int DEPTH = 3;
+    // (DEPTH 3 only for long-K weight-gradient launches (K >= 4096, chosen by the host), 2 elsewhere: the third stage costs
+    //  32-64 registers and a wave of occupancy, which the short skinny products need more than a deeper ring.  Same-box A/B:
+    //  depth 2 everywhere Versa 6.13 -> 5.83 ms but Cached 6.40 -> 6.45; depth 4 worse on both.)
+    constexpr int DEPTH = DEPTHV;
     f4 ra[DEPTH][TM / 16], rb[DEPTH][4];
     // FAST: this thread's element of K-tile 0 and the strides between its ROWS/16 loads / between K-tiles
     constexpr int TPRA = TM / 4, TPRB = TN / 4;
@@ -415,7 +418,16 @@ extern "C" void iisan_set_gemm32_tuning(int32_t tm_thresh, int32_t splitk_target
 }
 
 template <int FLAGS>
-int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, hipStream_t s) {
+int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bool deep, hipStream_t s) {
+    if constexpr ((FLAGS & (G32_TA | G32_TB)) == (G32_TA | G32_TB)) {
+        if (deep && fast) {          // long-K weight gradients: three K-tiles in flight
+            if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64, true, 3>), grid, dim3(256), 0, s, b, epi);
+            else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32, true, 3>), grid, dim3(256), 0, s, b, epi);
+            else hipLaunchKernelGGL((gemm32_kernel<FLAGS, 16, true, 3>), grid, dim3(256), 0, s, b, epi);
+            IISAN_LAUNCH_OK();
+            return IISAN_OK;
+        }
+    }
     if (fast) {
         if (tm == 64) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 64, true>), grid, dim3(256), 0, s, b, epi);
         else if (tm == 32) hipLaunchKernelGGL((gemm32_kernel<FLAGS, 32, true>), grid, dim3(256), 0, s, b, epi);
@@ -532,7 +544,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     const int epi = via_scratch ? 0 : (flags & ~(G32_TA | G32_TB | G32_ACCUM));
     int rc;
     switch (structural) {
-#define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, s); break
+#define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, min_k >= 4096, s); break
         G32_CASE(0);
         G32_CASE(G32_TA);
         G32_CASE(G32_TB);
