@@ -249,6 +249,9 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     stagger(args.stagger * (int)blockIdx.y);
     const int64_t ntiles = (args.M + R - 1) / R;
     float gate_part = 0.f;
+    float dbu_acc[D / NT], dbd_acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < D / NT; ++i) dbu_acc[i] = 0.f;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t m0 = tile * R;
 
@@ -273,13 +276,16 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     }
     __syncthreads();
 
-    // db_u += colsum(dO): one thread per column, fixed row order inside the tile
+    // db_u += colsum(dO): one thread per column, fixed row order inside the tile; the thread -> column assignment is the same
+    // for every tile of this persistent workgroup, so the sums stay in registers and ONE atomic per column and workgroup
+    // goes out at the end (one per column and TILE was 1.6 M atomics per Cached launch)
     if (t.dbu) {
-        for (int c = tid; c < D; c += NT) {
+#pragma unroll
+        for (int i = 0; i < D / NT; ++i) {
             float s = 0.f;
 #pragma unroll
-            for (int row = 0; row < R; ++row) s += Gs[row * FS + c];
-            unsafeAtomicAdd(t.dbu + c, s);
+            for (int row = 0; row < R; ++row) s += Gs[row * FS + tid + i * NT];
+            dbu_acc[i] += s;
         }
     }
 
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
         float s = 0.f;
 #pragma unroll
         for (int row = 0; row < R; ++row) s += Ds[row * UST + tid];
-        unsafeAtomicAdd(t.dbd + tid, s);
+        dbd_acc += s;
     }
 
     // ---- 3. dF = dO + dU · Wd, in place in LDS ---------------------------------------------------------------------------
@@ -349,6 +355,11 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     gate_part += part;
     __syncthreads();          // the tile buffers are rewritten by the next tile's phase 1
     }
+    if (t.dbu) {
+#pragma unroll
+        for (int i = 0; i < D / NT; ++i) unsafeAtomicAdd(t.dbu + tid + i * NT, dbu_acc[i]);
+    }
+    if (t.dbd && tid < RD) unsafeAtomicAdd(t.dbd + tid, dbd_acc);
     if (gated) {              // one atomic per workgroup for all its tiles
         gate_part = wave_sum(gate_part);
         if (lane == 0) red[wave] = gate_part;
