@@ -609,6 +609,10 @@ def test_versa_packed_tap_store(variant):
     l_st = model(ids, None, None, b.log_mask.cuda(), 0)
     assert torch.equal(l_ref2, l_st)
     assert torch.isfinite(l_ref) and torch.isfinite(l_st)
+    # the Versa side network on the DISTINCT ids only (`dedup_items`): rows are independent, the loss must not move a bit
+    model.dedup_items = True
+    l_dd = model(ids, None, None, b.log_mask.cuda(), 0)
+    assert torch.equal(l_st, l_dd)
 
 
 @pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
