@@ -262,6 +262,11 @@ struct Gemm32Prob {
     int32_t lda, ldb, ldc, ldr;
     DropCfg drop;          // G32_DROPOUT: C = dropout(acc + bias [act]) (+ resid); element index = m*ldc + n
     int64_t ksplit_stride; // internal (split-K through a scratch buffer): K-split y writes its raw partial product at C + y*ksplit_stride
+    // gemm_x3 only: caller-owned amax slots of the operands (bit pattern of max|x|, zeroed by the caller before their first
+    // use) and whether they already hold the tensor's amax — a tensor read by several products (an activation by its forward
+    // and weight-gradient products, a weight by forward and dX) then pays its amax pass once.  null = private slot, computed here.
+    uint32_t* amax_a; uint32_t* amax_b;
+    int32_t amax_a_ready, amax_b_ready;
 };
 // Scratch for split-K of skinny long-K products that are NOT "+=" (their epilogue — bias, activation, masks — has to see the
 // complete sum, so the partial products meet in a buffer and a reducer applies it).  Registered by an executor for the

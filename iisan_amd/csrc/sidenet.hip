@@ -202,6 +202,10 @@ struct SideBufs {
     void* x3; size_t x3_bytes;       // scratch of the split-operand GEMM (operand images + scales), null = not used
     float* WT[3][2];                 // backward of the fused SANB step: fc_down^T [D, 64] and fc_up^T [64, D] of the current step
     float* skws; size_t skws_floats; // split-K scratch of the skinny long-K products (gemm32_set_scratch)
+    // amax slots shared by the split-operand products that read the same tensor: [0..2] final tower state O_z, [3..5] fc weight,
+    // [6..8] dY_z, [9 + i] the wide tap of dim-align step i.  Forward zeroes and fills 0..5 and 9.., backward reuses them
+    // (same workspace, tensors unchanged) and owns 6..8.
+    uint32_t* amax;
 };
 
 // 1 (default): the large Linear layers (fc_z, Versa dim-align; forward, dX and dW) run as split-operand fp16 MFMA GEMMs
@@ -259,6 +263,7 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         if (wg > b.skws_floats) b.skws_floats = wg;
     }
     b.skws = c.take<float>(b.skws_floats);
+    b.amax = c.take<uint32_t>(16 + IISAN_MAX_SIDE);
     b.x3_bytes = x3_need(p, M);
     b.x3 = b.x3_bytes ? (void*)c.take<char>(b.x3_bytes) : nullptr;
 }
@@ -412,12 +417,14 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     ScratchGuard guard(b.skws, b.skws_floats);
     const int act_flag = cfg->gelu ? G32_GELU : G32_RELU;
     const int nsteps = p.diff_cv + p.diff_t + p.n[2];
+    IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE) * sizeof(uint32_t), s));
     for (int g = 0; g < nsteps; ++g) {
         const StepMap sm = step_map(p, g);
         if (sm.mm_i >= 0 && p.align) {        // dim-align the wider modality's tap (Code_Cached_Asym/model/model.py:404-411)
             const int zw = p.text_wide ? 1 : 0;
             Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
                                  b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
+            pd.amax_a = b.amax + 9 + sm.mm_i;        // the tap's amax: read again by the weight-gradient product of this step
             IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
         }
         if (step_fusable(p, sm)) {            // fusion + down + activation + up of every active tower in one launch
@@ -455,7 +462,11 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
         IISAN_TRY(launch_gemm32(pr, sm.nact, 0, s));
     }
     Gemm32Prob pr[3];
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
+    for (int z = 0; z < 3; ++z) {
+        pr[z] = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
+        pr[z].amax_a = b.amax + z;                   // O_z and the fc weight: their amax is left for the backward products
+        pr[z].amax_b = b.amax + 3 + z;
+    }
     IISAN_TRY(gemm_group(pr, 3, 0, b, s));
     for (int z = 0; z < 3; ++z) pr[z] = prob(b.Y[z], p.H[z], c.W(p.p_head[z]), p.H[z], c.W(p.p_head[z] + 1), item3 + z * p.E, 3 * p.E, M, p.E, p.H[z]);
     IISAN_TRY(launch_gemm32(pr, 3, 0, s));
@@ -484,9 +495,25 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     for (int z = 0; z < 3; ++z) { cs_x[z] = d_item3 + z * E; cs_o[z] = G(p.p_head[z] + 1); cs_n[z] = E; cs_ld[z] = 3 * E; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
     // fc: Y_z = O_z Wf^T + bf
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], c.W(p.p_fc[z]), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], p.H[z]);
+    IISAN_HIP_OK(hipMemsetAsync(b.amax + 6, 0, 3 * sizeof(uint32_t), s));
+    int fwd_x3[3];      // did the forward fc product of tower z take the split-operand route (and leave its operands' amax)?
+    for (int z = 0; z < 3; ++z) {
+        const Gemm32Prob f = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
+        fwd_x3[z] = (b.x3 && gemm_x3_applicable(f, 0)) ? 1 : 0;
+    }
+    for (int z = 0; z < 3; ++z) {
+        pr[z] = prob(b.dY[z], p.H[z], c.W(p.p_fc[z]), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], p.H[z]);
+        pr[z].amax_a = b.amax + 6 + z;                                            // dY_z: computed here, reused by dWf below
+        if (fwd_x3[z]) { pr[z].amax_b = b.amax + 3 + z; pr[z].amax_b_ready = 1; } // the fc weight: from the forward call
+    }
     IISAN_TRY(gemm_group(pr, 3, G32_TB, b, s));                                   // dO = dY · Wf
-    for (int z = 0; z < 3; ++z) pr[z] = prob(b.dY[z], p.H[z], b.O[p.n[z] - 1][z], p.D[z], nullptr, G(p.p_fc[z]), p.D[z], p.H[z], p.D[z], M);
+    int dy_ready[3];
+    for (int z = 0; z < 3; ++z) dy_ready[z] = (b.x3 && gemm_x3_applicable(pr[z], G32_TB)) ? 1 : 0;
+    for (int z = 0; z < 3; ++z) {
+        pr[z] = prob(b.dY[z], p.H[z], b.O[p.n[z] - 1][z], p.D[z], nullptr, G(p.p_fc[z]), p.D[z], p.H[z], p.D[z], M);
+        pr[z].amax_a = b.amax + 6 + z; pr[z].amax_a_ready = dy_ready[z];          // (zeroed above; filled by the dX product if it took this route)
+        if (fwd_x3[z]) { pr[z].amax_b = b.amax + z; pr[z].amax_b_ready = 1; }     // O_z: from the forward call
+    }
     IISAN_TRY(gemm_group(pr, 3, G32_TA | G32_TB | G32_ACCUM, b, s));              // dWf += dY^T · O
     for (int z = 0; z < 3; ++z) { cs_x[z] = b.dY[z]; cs_o[z] = G(p.p_fc[z] + 1); cs_n[z] = p.H[z]; cs_ld[z] = p.H[z]; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
@@ -575,6 +602,10 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
         if (need_dp) {                        // DP = tap_wide · Pd^T + bd
             const int zw = p.text_wide ? 1 : 0, i = sm.mm_i;
             Gemm32Prob pd = prob(b.dDP, p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
+            {
+                const Gemm32Prob f = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(i)), p.D[zw], c.W(p.dpw(i) + 1), b.DP[i], p.D[2], M, p.D[2], p.D[zw]);
+                if (b.x3 && gemm_x3_applicable(f, 0)) { pd.amax_b = b.amax + 9 + i; pd.amax_b_ready = 1; }   // the tap: from the forward dim-align product
+            }
             IISAN_TRY(gemm_group(&pd, 1, G32_TA | G32_TB | G32_ACCUM | G32_HINT_B_EXACT16, b, s));     // dPd += dDP^T · tap
             const float* X[1] = {b.dDP};
             float* O[1] = {G(p.dpw(i) + 1)};

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
-                  int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s) {
+                  int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s,
+                  bool amax_ready = false) {
     SplitArgs a{};
     a.lo_flag = lo_flag;
     a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.pattern = pattern; a.trans = trans ? 1 : 0;
@@ -186,8 +187,10 @@ int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_
     int64_t blocks = ceil_div(a.rows * (a.cols / 4), 256 * 4);
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, a.rows, a.cols, ld, amax_bits);
-    IISAN_LAUNCH_OK();
+    if (!amax_ready) {
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, a.rows, a.cols, ld, amax_bits);
+        IISAN_LAUNCH_OK();
+    }
     if (!trans) {
         int64_t b2 = ceil_div(out_rows * (kp / 8), 256);
         if (b2 > 8192) b2 = 8192;
@@ -266,9 +269,11 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_
     // taps cached in fp16 — goes LAST, so the GEMM can drop the last third of K when the device-side flag says so
     const bool b_last = (flags & G32_HINT_B_EXACT16) != 0;
     flags &= ~G32_HINT_B_EXACT16;
-    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, b_last ? 1 : 0, A16, mp, kp, amax, inv, lo_flag, s));
+    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, b_last ? 1 : 0, A16, mp, kp, p.amax_a ? p.amax_a : amax, inv, lo_flag, s,
+                            p.amax_a && p.amax_a_ready));
     // B operand rows = N: stored [N,K] by default, [K,N] under G32_TB (then the operand is the source transposed)
-    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, b_last ? 0 : 1, B16, np, kp, amax + 1, inv + 1, lo_flag + 1, s));
+    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, b_last ? 0 : 1, B16, np, kp, p.amax_b ? p.amax_b : amax + 1, inv + 1, lo_flag + 1, s,
+                            p.amax_b && p.amax_b_ready));
     Gemm16Args g{};
     g.A = A16; g.W = B16; g.bias = p.bias; g.out = p.C; g.resid = p.resid;
     g.M = p.M; g.N = p.N; g.K = (int32_t)(3 * kp); g.lda = g.ldw = (int32_t)(3 * kp); g.ldo = p.ldc;
