@@ -97,6 +97,7 @@ EXTRA_SIGNATURES = {
     "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_set_gemm32_accum_scratch": (None, [i32]),
     "iisan_set_gemm32_tuning": (None, [i32, i32]),
+    "iisan_set_gemm32_k64": (None, [i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),
 }
@@ -126,6 +127,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent: loud by design
         fn.restype = res
         fn.argtypes = args
+    # development aid (profiling a non-default route under rocprofv3): IISAN_DEV_KNOBS="sanb_fused=0,gemm32_k64=1" calls the
+    # one-argument iisan_set_<name>(int) knobs once at load time.  Unset in every product, test and bench run.
+    for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")):
+        name, val = kv.split("=")
+        getattr(lib, "iisan_set_" + name.strip())(int(val))
     _lib = lib
     return lib
 

@@ -322,6 +322,135 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
         }
 }
 
+// ---- K = 64 products with a wide N: the up projection of a SANB and its dF product -------------------------------------------
+//   C[M, N] = A[M, 64] · op(W) (+ bias) (+ resid),   op(W): W stored [N, 64] (default) or [64, N] (TBV)
+// The tiled kernel above gives these ONE K-tile per workgroup — operand round trip, 64 MFMAs, epilogue, exit — with nothing in
+// flight meanwhile: Versa's text tower ([1408, 64] x [64 -> 8192] + F, 92 MB of HBM traffic, 1.5 GFLOP) took 67 us, 34 us even
+// without the residual (tools/gemm32_wide.py), against ~18 us of HBM time and ~10 us of f32-matrix time.  Here a workgroup owns
+// 64 rows x (64 * nblk) columns: its slice of W goes through LDS ONCE and is shared by the four waves, wave w keeps rows
+// 16 w ..+15 of A in registers as the B operand of TRANSPOSED products (weights are the A operand, so a lane ends up with
+// consecutive output columns of one row) and walks the slice in 64-column blocks: 16 ds_read_b128, the block's residual / bias
+// reads, 64 MFMAs, 16-byte stores (64 contiguous bytes per row and instruction).  (A first version streamed W from L2 per
+// 16-ROW tile, four waves side by side on different columns: 36 TF at any size — every 16 rows re-read all of W, 1.5 GB per
+// launch at M = 11,264, and the chip delivers ~5 TB/s of such reads)
+// Any assignment of the contraction index to (MFMA step, lane group g) works as long as both operands use the same one; it is
+// chosen per layout so that every LDS read is a 16-byte one:
+//   W [N, 64]:  LDS [col][68]; step (s, e) contracts k = 16 s + 4 g + e — lane (i, g) reads W[16 f + i][16 s + 4 g ..+3] for fragment f
+//   W [64, N]:  LDS [k][cols + 4]; step s contracts k = 16 g + s — lane (i, g) reads W[16 g + s][4 q(i) ..+3], q(i) = 4 (i & 3) + (i >> 2):
+//               the four values feed four fragments e whose feature rows are {4 q(i') + e}; a lane's results for register r
+//               are then the columns 16 r + 4 g ..+3 of the block — contiguous over e.
+// Exact fp32 (v_mfma_f32_16x16x4_f32), fixed summation order.  In place (C == resid) is fine: a lane reads exactly the elements
+// it later writes.
+struct K64Prob { const float* A; const float* W; const float* bias; const float* resid; float* C; int64_t M; int32_t N, lda, ldw, ldc, ldr; };
+struct K64Batch { K64Prob p[4]; };
+
+template <bool TBV>
+__global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const K64Prob& p = batch.p[blockIdx.z];
+    const int c0 = (int)blockIdx.y * nblk * 64;                     // first column of the slice
+    if ((int64_t)blockIdx.x * 64 >= p.M || c0 >= p.N) return;       // block-uniform
+    int nb = (p.N - c0) >> 6;
+    nb = nb < nblk ? nb : nblk;
+    const int cols = nb * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    // ---- the slice of W -> LDS (all requests first, then the writes) ---------------------------------------------------------
+    const int stride = TBV ? cols + 4 : 68;
+    {
+        const int per_row = TBV ? cols / 4 : 16;                    // 16-byte pieces per source row
+        const int pieces = 16 * cols;                               // 64 x cols floats
+        f4 t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int id = tid + 256 * q;
+            id = id < pieces ? id : pieces - 1;
+            const int r = id / per_row, c = id - r * per_row;
+            t[q] = TBV ? *(const f4*)(p.W + (int64_t)r * p.ldw + c0 + 4 * c) : *(const f4*)(p.W + (int64_t)(c0 + r) * p.ldw + 4 * c);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int id = tid + 256 * q;
+            if (id < pieces) {
+                const int r = id / per_row, c = id - r * per_row;
+                *(f4*)(wlds + r * stride + 4 * c) = t[q];
+            }
+        }
+    }
+    const bool has_r = p.resid != nullptr, has_b = p.bias != nullptr;
+    const float* wl = wlds + (TBV ? (16 * g) * stride + 4 * (4 * (j & 3) + (j >> 2)) : j * stride + 4 * g);
+    __syncthreads();
+    // ---- the workgroup's row tiles (64 rows each: wave w rows 16 w ..+15), the slice stays in LDS ------------------------------
+#pragma unroll 1
+    for (int64_t m0 = (int64_t)blockIdx.x * 64; m0 < p.M; m0 += (int64_t)gridDim.x * 64) {
+    const int64_t mj = m0 + 16 * wave + j;
+    const int64_t mrow = mj < p.M ? mj : p.M - 1;                   // rows past M compute row M-1 again and are not stored
+    const bool live = mj < p.M;
+    // the wave's operand: this lane's 16 contraction values of row j
+    f4 xa[4];
+    {
+        const float* ar = p.A + mrow * p.lda + (TBV ? 16 * g : 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = *(const f4*)(ar + (TBV ? 4 * q : 16 * q));
+    }
+    const int ocol = c0 + 4 * g;                                    // + 64 * block + 16 * piece
+    float* crow = p.C + mrow * p.ldc + ocol;
+    // a missing residual / bias reads C / W instead and is discarded by a select: no branch between the loads
+    const float* rrow = has_r ? p.resid + mrow * p.ldr + ocol : crow;
+    const float* brow = has_b ? p.bias + ocol : p.W + 4 * g;
+    f4 rn[4];                                                       // residual of the next block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rn[q] = *(const f4*)(rrow + 16 * q);
+#pragma unroll 1
+    for (int t = 0; t < nb; ++t) {
+        f4 wc[16];
+        {
+            const float* wb = wl + (TBV ? 64 * t : 64 * t * stride);
+#pragma unroll
+            for (int q1 = 0; q1 < (TBV ? 16 : 4); ++q1)
+#pragma unroll
+                for (int q2 = 0; q2 < (TBV ? 1 : 4); ++q2)
+                    wc[TBV ? q1 : 4 * q1 + q2] = *(const f4*)(wb + q1 * (TBV ? stride : 16 * stride) + 16 * q2);
+        }
+        f4 rv[4], bv[4];
+        const int tn = t + 1 < nb ? t + 1 : t;                      // unconditional: the last block re-requests itself
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rv[q] = rn[q];
+            bv[q] = *(const f4*)(brow + 64 * t + 16 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rn[q] = *(const f4*)(rrow + 64 * tn + 16 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (f4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (TBV) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s][e], xa[s >> 2][s & 3], acc[e], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[4 * f + s][e], xa[s][e], acc[f], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // piece q = columns 64 t + 16 q + 4 g ..+3 of row j:  TBV: register q of the four fragments;  else fragment q
+            const f4 v = TBV ? (f4){acc[0][q], acc[1][q], acc[2][q], acc[3][q]} : acc[q];
+            const f4 z = {0.f, 0.f, 0.f, 0.f};
+            if (live) *(f4*)(crow + 64 * t + 16 * q) = v + ((has_b ? bv[q] : z) + (has_r ? rv[q] : z));
+        }
+    }
+    }
+}
+
 // column sums: out[n] += sum_m X[m][n]  (bias gradients); up to 4 problems per launch
 struct ColsumBatch {
     const float* X[4];
@@ -441,6 +570,10 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bo
 
 }  // namespace
 
+// 1 (default): K = 64 products with a wide N and a plain epilogue take gemm32_k64_kernel; 0: the tiled kernel.  Test / bench knob.
+static int g_use_k64 = 1;
+extern "C" void iisan_set_gemm32_k64(int32_t on) { g_use_k64 = on; }
+
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
 
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
@@ -451,6 +584,45 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
         b.p[i] = probs[i];
         IISAN_CHECK_SHAPE(probs[i].M > 0 && probs[i].N > 0 && probs[i].K > 0, "gemm32: empty problem %d", i);
         if (probs[i].K < min_k) min_k = probs[i].K;
+    }
+    // K = 64 products with a wide N and a plain epilogue (bias / residual): gemm32_k64_kernel
+    if ((flags & ~G32_TB) == 0 && g_use_k64) {
+        bool ok = true;
+        int64_t maxM = 0;
+        int maxnb = 0;
+        K64Batch kb{};
+        for (int i = 0; i < nprob && ok; ++i) {
+            const Gemm32Prob& q = probs[i];
+            ok = q.K == 64 && q.N >= 256 && (q.N & 63) == 0 && !q.act_src && q.ksplit_stride == 0 &&
+                 (q.lda & 3) == 0 && (q.ldb & 3) == 0 && (q.ldc & 3) == 0 && (!q.resid || (q.ldr & 3) == 0) &&
+                 (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.resid | (uintptr_t)q.bias) & 15) == 0;
+            kb.p[i] = K64Prob{q.A, q.B, q.bias, q.resid, q.C, q.M, q.N, q.lda, q.ldb, q.ldc, q.ldr};
+            if (q.M > maxM) maxM = q.M;
+            if ((q.N >> 6) > maxnb) maxnb = q.N >> 6;
+        }
+        if (ok) {
+            const int64_t rt = ceil_div(maxM, 64);
+            int nblk = 4;                                    // 64-column blocks per workgroup: fewer while the launch is small
+            while (nblk > 1 && rt * ceil_div(maxnb, nblk) * nprob < 1024) nblk >>= 1;
+            // One 64-row tile per workgroup.  (Persistent workgroups that keep their W slice and walk several row tiles were
+            // slower at every size tried — Versa 5.86 vs 5.65 ms per step, Cached on this route 6.41 vs 6.25: a tile's operand
+            // and first residual round trips are exposed once per tile and the hardware's own workgroup dispatch balances better.)
+            const int64_t ny = ceil_div(maxnb, nblk);
+            IISAN_CHECK_SHAPE(rt < (1ll << 31), "gemm32: grid too large");
+            const dim3 grid((unsigned)rt, (unsigned)ny, (unsigned)nprob);
+            const size_t lds = (size_t)64 * (64 * nblk + 4) * sizeof(float) > (size_t)64 * nblk * 68 * sizeof(float)
+                                   ? (size_t)64 * (64 * nblk + 4) * sizeof(float) : (size_t)64 * nblk * 68 * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
+                IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
+                attr_set = true;
+            }
+            if (flags & G32_TB) hipLaunchKernelGGL(gemm32_k64_kernel<true>, grid, dim3(256), lds, s, kb, nblk);
+            else hipLaunchKernelGGL(gemm32_k64_kernel<false>, grid, dim3(256), lds, s, kb, nblk);
+            IISAN_LAUNCH_OK();
+            return IISAN_OK;
+        }
     }
     auto tiles_for = [&](int tm) {
         int64_t mt = 0;

@@ -44,7 +44,11 @@ def test_gemm32_misaligned_operands_take_the_generic_fetch(lib):
                                   (256, 128, 128, 1, 0), (64, 768, 2816, 1, 1),
                                   # long K ranges on 64 / 32 / 16-row tiles
                                   (256, 128, 1024, 1, 0), (192, 128, 640, 0, 1), (96, 64, 576, 0, 0), (2816, 192, 512, 0, 0),
-                                  (1408, 1024, 8192, 0, 0)])
+                                  (1408, 1024, 8192, 0, 0),
+                                  # K = 64 with a wide N: the register-resident row-tile kernel (gemm32_k64_kernel), both weight
+                                  # layouts, ragged rows, column counts that leave waves / workgroups without a block
+                                  (1408, 8192, 64, 0, 0), (1408, 8192, 64, 0, 1), (37, 256, 64, 0, 0), (16, 1024, 64, 0, 1),
+                                  (2000, 320, 64, 0, 0), (11264, 768, 64, 0, 1)])
 def test_gemm32_vs_torch(lib, case):
     M, N, K, ta, tb = case
     g = torch.Generator().manual_seed(M + N + K)
