@@ -267,6 +267,7 @@ struct Gemm32Prob {
     // and weight-gradient products, a weight by forward and dX) then pays its amax pass once.  null = private slot, computed here.
     uint32_t* amax_a; uint32_t* amax_b;
     int32_t amax_a_ready, amax_b_ready;
+    uint32_t* x3_zeroed;   // gemm_x3 only: 12 words the caller has zeroed for this product alone (private amax, 1/scale, lo flags); null = zeroed here
 };
 // Scratch for split-K of skinny long-K products that are NOT "+=" (their epilogue — bias, activation, masks — has to see the
 // complete sum, so the partial products meet in a buffer and a reducer applies it).  Registered by an executor for the

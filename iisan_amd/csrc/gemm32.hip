@@ -487,9 +487,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
 }
 
 // C = epilogue(sum_y P[y] + bias) (+ resid): the split-K partial products of up to 4 problems, fixed summation order
-struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; };
-__global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int ks, int epi) {
+// ns[z] = the K-splits of problem z that own a non-empty K range: only those wrote a partial (a shorter K than its launch
+// mates' leaves the rest of the scratch slots untouched — they are never read, so the scratch needs no zeroing)
+struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; int32_t ns[4]; };
+__global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int ks_launch, int epi) {
     const Gemm32Prob& p = rb.p[blockIdx.z];
+    const int ks = ks_launch < rb.ns[blockIdx.z] ? ks_launch : rb.ns[blockIdx.z];
     const float* P = rb.P[blockIdx.z];
     const int64_t stride = rb.stride[blockIdx.z], total = p.M * p.N;
     if (epi == 0 && !p.bias && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.resid || (p.ldr & 3) == 0)) {
@@ -666,7 +669,6 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
                 q.ksplit_stride = (int64_t)align_up((size_t)(q.M * q.N), 64);
                 off += ks * q.ksplit_stride;
             }
-            IISAN_HIP_OK(hipMemsetAsync(g_scratch, 0, (size_t)need * sizeof(float), s));     // a K-split beyond a short problem's K writes nothing
             splitk = ks;
             via_scratch = true;
         }
@@ -684,11 +686,7 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
             splitk = (int)ceil_div(ktiles, per);
         }
         int64_t need = 0;
-        bool same_k = true;
-        for (int i = 0; i < nprob; ++i) {
-            need += (int64_t)splitk * (int64_t)align_up((size_t)(probs[i].M * probs[i].N), 64);
-            same_k = same_k && probs[i].K == probs[0].K;
-        }
+        for (int i = 0; i < nprob; ++i) need += (int64_t)splitk * (int64_t)align_up((size_t)(probs[i].M * probs[i].N), 64);
         if ((size_t)need <= g_scratch_floats) {
             int64_t off = 0;
             for (int i = 0; i < nprob; ++i) {
@@ -700,7 +698,6 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
                 orig.p[i].ldr = orig.p[i].ldc;
                 orig.p[i].bias = nullptr;
             }
-            if (!same_k) IISAN_HIP_OK(hipMemsetAsync(g_scratch, 0, (size_t)need * sizeof(float), s));   // a K-split beyond a short problem's K writes nothing
             via_scratch = true;
             structural &= ~G32_ACCUM;
         }
@@ -735,6 +732,10 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
         rb.p[i] = orig.p[i];
         rb.P[i] = b.p[i].C;
         rb.stride[i] = b.p[i].ksplit_stride;
+        {   // the kernel gives split y the K-tiles [y, y+1) * ceil(ktiles / splits)
+            const int64_t ktiles = ceil_div(orig.p[i].K, (int64_t)TK), per = ceil_div(ktiles, (int64_t)splitk);
+            rb.ns[i] = (int32_t)ceil_div(ktiles, per);
+        }
         if (orig.p[i].M * orig.p[i].N > max_mn) max_mn = orig.p[i].M * orig.p[i].N;
     }
     int64_t blocks = ceil_div(max_mn, 256);

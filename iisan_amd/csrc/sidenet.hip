@@ -203,10 +203,16 @@ struct SideBufs {
     float* WT[3][2];                 // backward of the fused SANB step: fc_down^T [D, 64] and fc_up^T [64, D] of the current step
     float* skws; size_t skws_floats; // split-K scratch of the skinny long-K products (gemm32_set_scratch)
     // amax slots shared by the split-operand products that read the same tensor: [0..2] final tower state O_z, [3..5] fc weight,
-    // [6..8] dY_z, [9 + i] the wide tap of dim-align step i.  Forward zeroes and fills 0..5 and 9.., backward reuses them
-    // (same workspace, tensors unchanged) and owns 6..8.
+    // [9 + i] the wide tap of dim-align step i (6..8 unused).  Forward zeroes and fills them, backward reuses them (same
+    // workspace, tensors unchanged); the amax of dY_z lives in the backward block zb[0..2].
     uint32_t* amax;
+    // per-product scratch words of the split-operand GEMM (private amax, 1/scale, lo-plane flags: 12 words each), zeroed by the
+    // SAME memset as the amax slots of the call instead of one 48-byte memset per product (a fill kernel is ~5 us: 23 of them per
+    // Versa step).  Forward block: amax[16 + MAX_SIDE] | slots; backward block (zb): dY amax [3] + pad | slots.
+    uint32_t* x3z_f; uint32_t* zb; uint32_t* x3z_b;
+    mutable uint32_t* x3z_next; mutable int x3z_left;
 };
+constexpr int X3Z_WORDS = 12, X3Z_SLOTS_F = IISAN_MAX_SIDE + 4, X3Z_SLOTS_B = IISAN_MAX_SIDE + 8, ZB_HEAD = 4;
 
 // 1 (default): the large Linear layers (fc_z, Versa dim-align; forward, dX and dW) run as split-operand fp16 MFMA GEMMs
 // (split.hip); 0: everything on the f32-input matrix cores (gemm32.hip).  Test / bench knob.
@@ -263,7 +269,13 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         if (wg > b.skws_floats) b.skws_floats = wg;
     }
     b.skws = c.take<float>(b.skws_floats);
-    b.amax = c.take<uint32_t>(16 + IISAN_MAX_SIDE);
+    {   // one carve per direction: [amax | slots] and [dY amax | slots] are each zeroed by a single memset
+        uint32_t* zf = c.take<uint32_t>(16 + IISAN_MAX_SIDE + X3Z_WORDS * X3Z_SLOTS_F);
+        b.amax = zf; b.x3z_f = zf ? zf + 16 + IISAN_MAX_SIDE : nullptr;
+        b.zb = c.take<uint32_t>(ZB_HEAD + X3Z_WORDS * X3Z_SLOTS_B);
+        b.x3z_b = b.zb ? b.zb + ZB_HEAD : nullptr;
+        b.x3z_next = nullptr; b.x3z_left = 0;
+    }
     b.x3_bytes = x3_need(p, M);
     b.x3 = b.x3_bytes ? (void*)c.take<char>(b.x3_bytes) : nullptr;
 }
@@ -273,7 +285,11 @@ int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStr
     Gemm32Prob rest[4];
     int nr = 0;
     for (int i = 0; i < n; ++i) {
-        if (b.x3 && gemm_x3_applicable(pr[i], flags)) IISAN_TRY(launch_gemm_x3(pr[i], flags, b.x3, b.x3_bytes, s));
+        if (b.x3 && gemm_x3_applicable(pr[i], flags)) {
+            Gemm32Prob q = pr[i];
+            if (b.x3z_left > 0) { q.x3_zeroed = b.x3z_next; b.x3z_next += X3Z_WORDS; --b.x3z_left; }
+            IISAN_TRY(launch_gemm_x3(q, flags, b.x3, b.x3_bytes, s));
+        }
         else rest[nr++] = pr[i];
     }
     if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags & ~G32_HINT_B_EXACT16, s));
@@ -417,7 +433,8 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     ScratchGuard guard(b.skws, b.skws_floats);
     const int act_flag = cfg->gelu ? G32_GELU : G32_RELU;
     const int nsteps = p.diff_cv + p.diff_t + p.n[2];
-    IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE) * sizeof(uint32_t), s));
+    IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE + X3Z_WORDS * X3Z_SLOTS_F) * sizeof(uint32_t), s));
+    b.x3z_next = b.x3z_f; b.x3z_left = X3Z_SLOTS_F;
     for (int g = 0; g < nsteps; ++g) {
         const StepMap sm = step_map(p, g);
         if (sm.mm_i >= 0 && p.align) {        // dim-align the wider modality's tap (Code_Cached_Asym/model/model.py:404-411)
@@ -495,7 +512,8 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     for (int z = 0; z < 3; ++z) { cs_x[z] = d_item3 + z * E; cs_o[z] = G(p.p_head[z] + 1); cs_n[z] = E; cs_ld[z] = 3 * E; }
     IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, 3, s));
     // fc: Y_z = O_z Wf^T + bf
-    IISAN_HIP_OK(hipMemsetAsync(b.amax + 6, 0, 3 * sizeof(uint32_t), s));
+    IISAN_HIP_OK(hipMemsetAsync(b.zb, 0, (size_t)(ZB_HEAD + X3Z_WORDS * X3Z_SLOTS_B) * sizeof(uint32_t), s));
+    b.x3z_next = b.x3z_b; b.x3z_left = X3Z_SLOTS_B;
     int fwd_x3[3];      // did the forward fc product of tower z take the split-operand route (and leave its operands' amax)?
     for (int z = 0; z < 3; ++z) {
         const Gemm32Prob f = prob(b.O[p.n[z] - 1][z], p.D[z], c.W(p.p_fc[z]), p.D[z], c.W(p.p_fc[z] + 1), b.Y[z], p.H[z], M, p.H[z], p.D[z]);
@@ -503,7 +521,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     }
     for (int z = 0; z < 3; ++z) {
         pr[z] = prob(b.dY[z], p.H[z], c.W(p.p_fc[z]), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], p.H[z]);
-        pr[z].amax_a = b.amax + 6 + z;                                            // dY_z: computed here, reused by dWf below
+        pr[z].amax_a = b.zb + z;                                                  // dY_z: computed here, reused by dWf below
         if (fwd_x3[z]) { pr[z].amax_b = b.amax + 3 + z; pr[z].amax_b_ready = 1; } // the fc weight: from the forward call
     }
     IISAN_TRY(gemm_group(pr, 3, G32_TB, b, s));                                   // dO = dY · Wf
@@ -511,7 +529,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     for (int z = 0; z < 3; ++z) dy_ready[z] = (b.x3 && gemm_x3_applicable(pr[z], G32_TB)) ? 1 : 0;
     for (int z = 0; z < 3; ++z) {
         pr[z] = prob(b.dY[z], p.H[z], b.O[p.n[z] - 1][z], p.D[z], nullptr, G(p.p_fc[z]), p.D[z], p.H[z], p.D[z], M);
-        pr[z].amax_a = b.amax + 6 + z; pr[z].amax_a_ready = dy_ready[z];          // (zeroed above; filled by the dX product if it took this route)
+        pr[z].amax_a = b.zb + z; pr[z].amax_a_ready = dy_ready[z];          // (zeroed above; filled by the dX product if it took this route)
         if (fwd_x3[z]) { pr[z].amax_b = b.amax + z; pr[z].amax_b_ready = 1; }     // O_z: from the forward call
     }
     IISAN_TRY(gemm_group(pr, 3, G32_TA | G32_TB | G32_ACCUM, b, s));              // dWf += dY^T · O

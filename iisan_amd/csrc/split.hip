@@ -261,10 +261,11 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_
     w += align_up((size_t)mp * 3 * kp * 2, 256);
     _Float16* B16 = (_Float16*)w;
     w += align_up((size_t)np * 3 * kp * 2, 256);
-    uint32_t* amax = (uint32_t*)w;            // [0] A, [1] B
-    float* inv = (float*)(w + 16);            // [0] A, [1] B
-    int32_t* lo_flag = (int32_t*)(w + 32);    // [0] A, [1] B: any non-zero lo element
-    IISAN_HIP_OK(hipMemsetAsync(amax, 0, 48, s));
+    char* z48 = p.x3_zeroed ? (char*)p.x3_zeroed : w;
+    uint32_t* amax = (uint32_t*)z48;          // [0] A, [1] B
+    float* inv = (float*)(z48 + 16);          // [0] A, [1] B
+    int32_t* lo_flag = (int32_t*)(z48 + 32);  // [0] A, [1] B: any non-zero lo element
+    if (!p.x3_zeroed) IISAN_HIP_OK(hipMemsetAsync(amax, 0, 48, s));
     // K' = [hi·hi | hi·lo | lo·hi]: the plane that may be all zeros — the lo plane of an operand that is exact in fp16, like
     // taps cached in fp16 — goes LAST, so the GEMM can drop the last third of K when the device-side flag says so
     const bool b_last = (flags & G32_HINT_B_EXACT16) != 0;

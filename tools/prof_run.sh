@@ -8,6 +8,7 @@ out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out -o bench -- python3 bench.py "$@" > $out/bench.log 2>&1
 python3 tools/rocpd_summary.py $(find $out -name "*.db" | head -1) > $out/summary.md 2>/dev/null
+python3 tools/rocpd_seq.py $(find $out -name "*.db" | head -1) > $out/sequence.txt 2>/dev/null
 find $out -name "*.db" -delete
 head -$rows $out/summary.md | cut -c1-200
 grep "^{" $out/bench.log | tail -1 | cut -c1-400
