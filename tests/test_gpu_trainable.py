@@ -48,7 +48,11 @@ def test_gemm32_misaligned_operands_take_the_generic_fetch(lib):
                                   # K = 64 with a wide N: the register-resident row-tile kernel (gemm32_k64_kernel), both weight
                                   # layouts, ragged rows, column counts that leave waves / workgroups without a block
                                   (1408, 8192, 64, 0, 0), (1408, 8192, 64, 0, 1), (37, 256, 64, 0, 0), (16, 1024, 64, 0, 1),
-                                  (2000, 320, 64, 0, 0), (11264, 768, 64, 0, 1)])
+                                  (2000, 320, 64, 0, 0), (11264, 768, 64, 0, 1),
+                                  # N = 64 with a long K (SANB down projection and its dU product), both weight layouts, ragged rows,
+                                  # K-tile counts 4 / 5 / 12 / 128 (ring tails, split-K through the scratch buffer)
+                                  (1408, 64, 8192, 0, 0), (1408, 64, 8192, 0, 1), (11264, 64, 768, 0, 0), (11264, 64, 768, 0, 1),
+                                  (100, 64, 256, 0, 0), (77, 64, 320, 0, 1)])
 def test_gemm32_vs_torch(lib, case):
     M, N, K, ta, tb = case
     g = torch.Generator().manual_seed(M + N + K)
