@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
             }
         }
     };
+    // FAST only: one of the NP = TM/16 + 4 loads of a K-tile.  Issued back to back ahead of the MFMAs, eight 16-byte loads per
+    // thread cost the f32 product loop a quarter of its matrix rate even when every one hits L1 (tools/micro/f32_loop.hip:
+    // 152 -> 115 TF; spread one by one among the MFMAs: 154) — so the fenced path below requests piece i after k-step 2 i + 1.
+    constexpr int NP = TM / 16 + 4;
+    // Addresses as wave-uniform base (SGPRs: operand + tile origin + K-tile) + one 32-bit lane offset per piece: between MFMAs a
+    // 64-bit per-lane address add per load costs matrix time (the first spread version made the weight-gradient products slower).
+    const float* const pa_u = TA ? p.A + kbeg * p.lda + m0 : p.A + m0 * p.lda + kbeg;
+    const float* const pb_u = TB ? p.B + kbeg * p.ldb + n0 : p.B + (int64_t)n0 * p.ldb + kbeg;
+    uint32_t voa[TM / 16], vob[4];
+#pragma unroll
+    for (int i = 0; i < TM / 16; ++i)
+        voa[i] = (uint32_t)(((TA ? (int64_t)(tid / TPRA) * p.lda + (tid % TPRA) * 4 : (int64_t)(tid >> 4) * p.lda + (tid & 15) * 4) + i * sia) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        vob[i] = (uint32_t)(((TB ? (int64_t)(tid / TPRB) * p.ldb + (tid % TPRB) * 4 : (int64_t)(tid >> 4) * p.ldb + (tid & 15) * 4) + i * sib) * 4);
+    auto fetch_piece = [&](int slot, int64_t k, int i) {
+        int64_t t = (k - kbeg) / TK;
+        t = t < last_t ? t : last_t;
+        if (i < TM / 16) ra[slot][i] = *(const f4*)((const char*)(pa_u + t * ska) + voa[i]);
+        else rb[slot][i - TM / 16] = *(const f4*)((const char*)(pb_u + t * skb) + vob[i - TM / 16]);
+    };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) fetch(u, kbeg + (int64_t)u * TK);
     for (int64_t kb = kbeg; kb < kend; kb += (int64_t)DEPTH * TK) {
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                 store_tile<TM>(As_, ra[u], TA, tid);
                 store_tile<TN>(Bs_, rb[u], TB, tid);
                 __syncthreads();
-                fetch(u, k0 + (int64_t)DEPTH * TK);
+                if constexpr (!FAST) fetch(u, k0 + (int64_t)DEPTH * TK);
                 const int ksteps = (kend - k0 >= TK) ? TK / 4 : (int)((kend - k0 + 3) / 4);      // zero-filled tail
                 auto kstep = [&](int ks0) {
 #pragma unroll
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
                                 acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mf], b[nf], acc[q][mf][nf], 0, 0, 0);
                     }
                 };
-                if (ksteps == TK / 4) {
+                if (FAST || ksteps == TK / 4) {
                     // full tile: the fragments of k-slice s+1 are read before the MFMAs of slice s, fenced — left alone hipcc
                     // puts each slice's reads directly in front of its MFMAs behind an lgkmcnt(0) (the LDS latency exposed
                     // TK/4 times per tile); reading the whole tile's fragments up front costs 60 registers and a wave of occupancy
@@ -227,6 +248,9 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
 #pragma unroll
                             for (int nf = 0; nf < FN; ++nf)
                                 acc[ks % KA][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mf], bc[nf], acc[ks % KA][mf][nf], 0, 0, 0);
+                        if constexpr (FAST) {
+                            if ((ks & 1) && (ks >> 1) < NP) fetch_piece(u, k0 + (int64_t)DEPTH * TK, ks >> 1);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int f = 0; f < FM; ++f) ac[f] = an[f];
