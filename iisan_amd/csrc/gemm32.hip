@@ -346,6 +346,119 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Batch batch, int epi)
         }
 }
 
+// ---- weight-gradient products: both operands K-major, K = number of rows (item slots) ---------------------------------------
+//   P_y[M, N] = A^T[M, Kr] · B[Kr, N]   over the K range Kr of split y;   A stored [K, M], B stored [K, N]   (G32_TA | G32_TB, raw
+//   split-K partials for gemm32_reduce_kernel — the "+=" products dWu += dO^T·A, dWd += dU^T·F of every SANB and the fc layers)
+// gemm32_kernel ran these at 65-75 TF: 64 ds_read_b32 and two barriers per K-tile, ring loads in a burst.  Here, per 64 x 64
+// output tile and K-tile of 64 rows:
+//   * both operand tiles are 64 K-rows of 64 floats: 16-byte loads (one piece per 8 MFMAs, two K-tiles ahead), ds_write_b128
+//     into a double-buffered [k][68] image — one barrier per K-tile;
+//   * the four waves split the K-TILE (wave w contracts rows 16 w ..+15 of it), each accumulates the whole 64 x 64 tile
+//     (16 accumulators): per k-step one ds_read_b128 per operand — lane (i, kq) takes the four consecutive columns 4 i ..+3 of
+//     row 16 w + 4 s + kq, which feed the four 16-row fragments {4 i' + e} — and 16 MFMAs: 8 LDS reads per 64 MFMAs;
+//   * the four waves' tiles meet in LDS once, at the end (fixed order: bit-reproducible), 16-byte stores.
+// Fragment e of A holds rows {4 i + e}, fragment e' of B columns {4 j + e'}: accumulator (e, e') register r of lane (j, g) is
+// element (16 g + 4 r + e, 4 j + e') — four consecutive columns over e'.
+__global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
+    __shared__ __attribute__((aligned(16))) float sm[2][2][64 * 64];          // [buffer][operand][k][64]   (64 KB)
+    const Gemm32Prob& p = batch.p[blockIdx.z];
+    const int tiles_n = p.N >> 6;
+    const int64_t tiles_m = p.M >> 6;
+    if ((int64_t)blockIdx.x >= tiles_m * tiles_n) return;
+    const int64_t tile_m = blockIdx.x / tiles_n;
+    const int tile_n = (int)(blockIdx.x - tile_m * tiles_n);
+    const int64_t m0 = tile_m * 64;
+    const int n0 = tile_n * 64;
+    const int64_t ktiles = p.K / TK;
+    const int64_t per = (ktiles + gridDim.y - 1) / gridDim.y;
+    const int64_t kt0 = (int64_t)blockIdx.y * per;
+    int64_t kt1 = kt0 + per;
+    if (kt1 > ktiles) kt1 = ktiles;
+    if (kt0 >= kt1) return;                                         // (the reducer knows which splits own rows)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    // staging: thread -> K-rows (tid >> 4) + 16 q, columns 4 (tid & 15) ..+3; wave-uniform base + one 32-bit lane offset per piece
+    const float* const a_u = p.A + kt0 * TK * p.lda + m0;
+    const float* const b_u = p.B + kt0 * TK * p.ldb + n0;
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        voa[q] = (uint32_t)((((int64_t)(tid >> 4) + 16 * q) * p.lda + (tid & 15) * 4) * 4);
+        vob[q] = (uint32_t)((((int64_t)(tid >> 4) + 16 * q) * p.ldb + (tid & 15) * 4) * 4);
+    }
+    const int64_t nt = kt1 - kt0;
+    f4 st[2][8];                                                    // two K-tiles of pieces in flight: [slot][A 0..3 | B 0..3]
+    auto piece = [&](int slot, int64_t t, int q) {
+        t = t < nt ? t : nt - 1;                                    // past the end: the last tile again (never staged)
+        if (q < 4) st[slot][q] = *(const f4*)((const char*)(a_u + t * TK * p.lda) + voa[q]);
+        else st[slot][q] = *(const f4*)((const char*)(b_u + t * TK * p.ldb) + vob[q - 4]);
+    };
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piece(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piece(1, 1, q);
+    f4 acc[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[e][f] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int sw = (tid >> 4) * 64 + (tid & 15) * 4;                // staging write offset (+ 16 * 64 q)
+    const int rd = (16 * wave + kq) * 64 + 4 * i16;                 // fragment read offset (+ 4 * 64 s)
+    auto tile = [&](int64_t t, int slot) {
+        float* bufA = sm[t & 1][0];
+        float* bufB = sm[t & 1][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(f4*)(bufA + sw + 16 * 64 * q) = st[slot][q];
+            *(f4*)(bufB + sw + 16 * 64 * q) = st[slot][4 + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        f4 a = *(const f4*)(bufA + rd), b = *(const f4*)(bufB + rd);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f4 an = *(const f4*)(bufA + rd + 4 * 64 * (s < 3 ? s + 1 : s)), bn = *(const f4*)(bufB + rd + 4 * 64 * (s < 3 ? s + 1 : s));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[f], acc[e][f], 0, 0, 0);
+                if (e & 1) {                                        // one piece of tile t + 2 after every 8th MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(slot, t + 2, 2 * s + (e >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a = an; b = bn;
+        }
+    };
+    int64_t t = 0;
+#pragma unroll 1
+    for (; t + 2 <= nt; t += 2) { tile(t, 0); tile(t + 1, 1); }
+    if (t < nt) tile(t, 0);
+    // ---- the four waves' tiles meet in LDS (64 KB = 4 x 16 KB), summed in wave order -----------------------------------------
+    __syncthreads();
+    float* red = &sm[0][0][0] + wave * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *(f4*)(red + (16 * kq + 4 * r + e) * 64 + 4 * i16) = (f4){acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
+    __syncthreads();
+    float* const Cp = p.C + (int64_t)blockIdx.y * p.ksplit_stride;
+    const float* all = &sm[0][0][0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = tid + 256 * q;                               // 1024 pieces of 16 bytes: row id >> 4, columns 4 (id & 15)
+        const int o = (id >> 4) * 64 + (id & 15) * 4;
+        const f4 v = (*(const f4*)(all + o) + *(const f4*)(all + 4096 + o)) + (*(const f4*)(all + 8192 + o) + *(const f4*)(all + 12288 + o));
+        *(f4*)(Cp + (m0 + (id >> 4)) * p.ldc + n0 + (id & 15) * 4) = v;
+    }
+}
+
 // ---- K = 64 products with a wide N: the up projection of a SANB and its dF product -------------------------------------------
 //   C[M, N] = A[M, 64] · op(W) (+ bias) (+ resid),   op(W): W stored [N, 64] (default) or [64, N] (TBV)
 // The tiled kernel above gives these ONE K-tile per workgroup — operand round trip, 64 MFMAs, epilogue, exit — with nothing in
@@ -598,7 +711,8 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bo
 }  // namespace
 
 // 1 (default): K = 64 products with a wide N and a plain epilogue take gemm32_k64_kernel; 0: the tiled kernel.  Test / bench knob.
-static int g_use_k64 = 1;
+static int g_use_k64 = 1, g_use_dw = 1;
+extern "C" void iisan_set_gemm32_dw(int32_t on) { g_use_dw = on; }
 extern "C" void iisan_set_gemm32_k64(int32_t on) { g_use_k64 = on; }
 
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
@@ -667,9 +781,17 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     }
     const int64_t max_tiles = tiles_for(TM);
     IISAN_CHECK_SHAPE(max_tiles < (1ll << 31), "gemm32: grid too large");
+    // weight-gradient shape on whole 64-tiles: gemm32_dw_kernel (needs the scratch route for its raw split-K partials)
+    bool dw_ok = g_use_dw && (flags & (G32_TA | G32_TB | G32_ACCUM)) == (G32_TA | G32_TB | G32_ACCUM) && (flags & ~(G32_TA | G32_TB | G32_ACCUM)) == 0 &&
+                 g_scratch && g_accum_via_scratch;
+    for (int i = 0; i < nprob && dw_ok; ++i) {
+        const Gemm32Prob& q = probs[i];
+        dw_ok = (q.M & 63) == 0 && (q.N & 63) == 0 && (q.K & 63) == 0 && q.K >= 4 * TK && (q.lda & 3) == 0 && (q.ldb & 3) == 0 &&
+                (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0;
+    }
     int splitk = 1;
     if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
-        const int64_t want = ceil_div(g_splitk_target, max_tiles * nprob);
+        const int64_t want = ceil_div(dw_ok ? 512 : g_splitk_target, max_tiles * nprob);     // gemm32_dw_kernel: two workgroups per CU
         const int64_t maxs = ceil_div(min_k, 2 * TK);
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (splitk < 1) splitk = 1;
@@ -736,6 +858,11 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     }
     const int epi = via_scratch ? 0 : (flags & ~(G32_TA | G32_TB | G32_ACCUM));
     int rc;
+    if (dw_ok && via_scratch && structural == (G32_TA | G32_TB)) {
+        hipLaunchKernelGGL(gemm32_dw_kernel, grid, dim3(256), 0, s, b);
+        IISAN_LAUNCH_OK();
+        rc = IISAN_OK;
+    } else
     switch (structural) {
 #define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, min_k >= 4096, s); break
         G32_CASE(0);
