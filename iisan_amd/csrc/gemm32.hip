@@ -791,7 +791,18 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
     }
     int splitk = 1;
     if (flags & G32_ACCUM) {   // weight-gradient shape: few tiles, long K -> spread K over the chip
-        const int64_t want = ceil_div(dw_ok ? 512 : g_splitk_target, max_tiles * nprob);     // gemm32_dw_kernel: two workgroups per CU
+        int64_t want = ceil_div(g_splitk_target, max_tiles * nprob);
+        if (dw_ok) {
+            // gemm32_dw_kernel: as many splits as give every CU ONE workgroup (nearest count).  Same-box sweep (tools/dw_ab.py):
+            // Cached (36 tiles, 176 K-tiles) 7 splits = 252 workgroups 5.95 ms, 14 = 504 (two per CU) 5.95, but 8 = 288 6.20,
+            // 10 = 360 6.07, 15 = 540 6.09 (a second, nearly empty round: 45.7 us per launch against 35.7) and 5 = 180 6.13;
+            // Versa (160 tiles, 22 K-tiles) 2 splits = 320 workgroups 5.45 ms, 3 = 480 5.55, 1 = 160 5.77.
+            int64_t sum_tiles = 0;
+            for (int i = 0; i < nprob; ++i) sum_tiles += (probs[i].M >> 6) * (probs[i].N >> 6);
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            want = ((int64_t)cus + sum_tiles / 2) / sum_tiles;
+        }
         const int64_t maxs = ceil_div(min_k, 2 * TK);
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (splitk < 1) splitk = 1;
