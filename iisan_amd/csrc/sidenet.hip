@@ -217,8 +217,12 @@ constexpr int X3Z_WORDS = 12, X3Z_SLOTS_F = IISAN_MAX_SIDE + 4, X3Z_SLOTS_B = II
 // 1 (default): the large Linear layers (fc_z, Versa dim-align; forward, dX and dW) run as split-operand fp16 MFMA GEMMs
 // (split.hip); 0: everything on the f32-input matrix cores (gemm32.hip).  Test / bench knob.
 int g_use_x3 = 1;
-// 1 (default): a SANB step whose active towers share a supported width runs as ONE fused launch per direction (sanb.hip);
-// 0: fusion kernel + separate GEMM launches.  Test / bench knob.
+// A SANB step whose active towers share a supported width can run as ONE fused launch per direction (sanb.hip) instead of the
+// fusion kernel + separate products.  1 (default): fused below SANB_FUSED_MAX_ROWS item slots, unfused from there on — same-box
+// A/B with the K = 64 and weight-gradient kernels of gemm32.hip in place: M = 1,408 (Uncached, bs = 128) fused 66.22 vs 66.37 ms,
+// M = 4,373 (Cached on distinct ids) unfused 4.33 vs 4.57 ms, M = 11,264 (Cached) unfused 5.95 vs 6.00 ms; 2: always fused;
+// 0: never.  Test / bench knob.
+constexpr int64_t SANB_FUSED_MAX_ROWS = 4096;
 int g_use_sanb = 1;
 
 size_t x3_need(const Plan& p, int64_t M) {
@@ -365,8 +369,8 @@ struct Ctx {
 };
 
 // the active towers of a step can share one fused launch
-bool step_fusable(const Plan& p, const StepMap& sm) {
-    if (!g_use_sanb) return false;
+bool step_fusable(const Plan& p, const StepMap& sm, int64_t M) {
+    if (!g_use_sanb || (g_use_sanb == 1 && M >= SANB_FUSED_MAX_ROWS)) return false;
     const int D = p.D[sm.z[0]];
     for (int a = 0; a < sm.nact; ++a)
         if (p.D[sm.z[a]] != D) return false;
@@ -444,7 +448,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             pd.amax_a = b.amax + 9 + sm.mm_i;        // the tap's amax: read again by the weight-gradient product of this step
             IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
         }
-        if (step_fusable(p, sm)) {            // fusion + down + activation + up of every active tower in one launch
+        if (step_fusable(p, sm, M)) {         // fusion + down + activation + up of every active tower in one launch
             SanbTowerDesc td[3];
             for (int a = 0; a < sm.nact; ++a) {
                 const int z = sm.z[a], k = sm.k[a];
@@ -540,7 +544,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     for (int g = nsteps - 1; g >= 0; --g) {
         const StepMap sm = step_map(p, g);
         const int na = sm.nact;
-        if (step_fusable(p, sm) && !(sm.mm_i >= 0 && p.align)) {
+        if (step_fusable(p, sm, M) && !(sm.mm_i >= 0 && p.align)) {
             // dWu += dO^T · A first (needs dO as it arrives), then ONE launch turns dO into dprev in place (tile-local:
             // a workgroup reads its rows of dO into LDS before it writes them) and leaves dU, db_u, db_d, dθ; dWd += dU^T · F last
             for (int a = 0; a < na; ++a) {

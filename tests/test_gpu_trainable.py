@@ -79,8 +79,8 @@ def test_gemm32_vs_torch(lib, case):
 
 @pytest.fixture
 def sanb_mode(lib, request):
-    """1 = product default: a SANB step runs as one fused launch per direction (`csrc/sanb.hip`); 0 = fusion kernel + separate
-    GEMM launches."""
+    """2 = a SANB step runs as one fused launch per direction (`csrc/sanb.hip`); 0 = fusion kernel + separate GEMM launches.  (The
+    product default, 1, picks by the number of item slots: fused below 4,096.)"""
     lib.iisan_set_sanb_fused(request.param)
     yield request.param
     lib.iisan_set_sanb_fused(1)
@@ -96,7 +96,7 @@ def x3_mode(lib, request):
     lib.iisan_set_x3(1)
 
 
-@pytest.mark.parametrize("sanb_mode", [1, 0], indirect=True)
+@pytest.mark.parametrize("sanb_mode", [2, 0], indirect=True)
 @pytest.mark.parametrize("x3_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("variant", ["default", "gelu", "rmfirst"])
 def test_cached_model_loss_and_grads_match_reference(variant, x3_mode, sanb_mode):
@@ -896,7 +896,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
     out = {}
     for alt in (False, True):
         lib.iisan_set_x3(2 if (alt and route == "x3") else 0)
-        lib.iisan_set_sanb_fused(1 if (alt and route == "sanb") else 0)
+        lib.iisan_set_sanb_fused(2 if (alt and route == "sanb") else 0)
         lib.iisan_set_gemm32_dw(0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
         try:
             kw = dict(drop_rate=0.0, adapter_activation="GELU")
