@@ -39,7 +39,8 @@ class SideCfg(C.Structure):
     _fields_ = [("n_side", i32), ("dim_cv", i32), ("dim_text", i32), ("down", i32), ("emb", i32),
                 ("gated", i32), ("gelu", i32), ("remove_first", i32), ("tap_stride_cv", i32),
                 ("tap_stride_text", i32), ("tap_index", i32 * MAX_SIDE), ("first_index", i32),
-                ("versa", i32), ("n_side_text", i32), ("tap_index_text", i32 * MAX_SIDE), ("first_index_text", i32)]
+                ("versa", i32), ("n_side_text", i32), ("tap_index_text", i32 * MAX_SIDE), ("first_index_text", i32),
+                ("taps_exact16", i32)]
 
 
 class SasrecCfg(C.Structure):

@@ -439,6 +439,11 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     const int nsteps = p.diff_cv + p.diff_t + p.n[2];
     IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE + X3Z_WORDS * X3Z_SLOTS_F) * sizeof(uint32_t), s));
     b.x3z_next = b.x3z_f; b.x3z_left = X3Z_SLOTS_F;
+    // taps known to be exact in fp16 (cfg->taps_exact16): their amax slots are PRESET to 8192.0f, which the split kernels turn into
+    // scale 1 (scale_of: amax in [2^13, 2^14) -> 2^0; an fp16 value cannot exceed 65504, so nothing overflows), and marked ready —
+    // the dim-align products skip the tap's amax pass (15 us each at Versa's [1408, 8192]), forward and weight gradient.
+    const bool taps_preset = cfg->taps_exact16 && p.align && p.n[2] > 0;
+    if (taps_preset) IISAN_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(b.amax + 9), 0x46000000, (size_t)p.n[2], s));
     for (int g = 0; g < nsteps; ++g) {
         const StepMap sm = step_map(p, g);
         if (sm.mm_i >= 0 && p.align) {        // dim-align the wider modality's tap (Code_Cached_Asym/model/model.py:404-411)
@@ -446,6 +451,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
                                  b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
             pd.amax_a = b.amax + 9 + sm.mm_i;        // the tap's amax: read again by the weight-gradient product of this step
+            pd.amax_a_ready = taps_preset ? 1 : 0;
             IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
         }
         if (step_fusable(p, sm, M)) {         // fusion + down + activation + up of every active tower in one launch

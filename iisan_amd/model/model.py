@@ -162,7 +162,7 @@ class CachedIISANAdaptedMModel(_SideNetBase):
         preceded by layer 0 when `remove_first` (the states are seeded with tap 0, model.py:215-218)."""
         return ([0] if self.remove_first else []) + list(self.side_cv_adapter_num_list)
 
-    def forward_item3_packed(self, taps_cv_sel, taps_text_sel):
+    def forward_item3_packed(self, taps_cv_sel, taps_text_sel, exact16: bool = False):
         """Taps that hold ONLY the layers this side network reads, in `packed_layers()` order
         (`iisan_amd.tapstore.TapStore.gather`): [M, n, 768] per modality instead of the reference's [.., 13, 768]."""
         o = 1 if self.remove_first else 0
@@ -205,6 +205,7 @@ class ModelMM(nn.Module):                          # model.py:14-105
         enc = self.mm_encoder
         if self.tap_stores is not None and getattr(enc, "cached", False) and sample_items_id is not None:
             st_cv, st_tx = self.tap_stores
+            ex16 = st_cv.table.dtype == torch.float16 and st_tx.table.dtype == torch.float16     # fp16 stores: exact taps
             if self.dedup_items:
                 # opt-in (SURVEY 8f-3 carried over to the Cached path): the side network and com_dense run once per DISTINCT
                 # item id of the batch — on Scientific-shaped batches 57 % of the slots are padding (id 0) and ~11 % of the
@@ -214,9 +215,9 @@ class ModelMM(nn.Module):                          # model.py:14-105
                 pad = (-uniq.numel()) % 64         # whole 64-row tiles for the K = rows weight-gradient products; the extra
                 if pad:                            # rows (copies of the first id) are gathered by nobody: zero gradient
                     uniq = torch.cat([uniq, uniq[:1].expand(pad)])
-                item3, _ = enc.forward_item3_packed(st_cv.gather(uniq), st_tx.gather(uniq))
+                item3, _ = enc.forward_item3_packed(st_cv.gather(uniq), st_tx.gather(uniq), exact16=ex16)
                 return self.fuse_item3(item3).index_select(0, inverse)
-            item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id))
+            item3, _ = enc.forward_item3_packed(st_cv.gather(sample_items_id), st_tx.gather(sample_items_id), exact16=ex16)
         elif hasattr(enc, "forward_item3"):
             if self.dedup_items and sample_items_id is not None and not getattr(enc, "cached", False):
                 item3, _ = enc.forward_item3(sample_items_images, sample_items_text, sample_items_id)

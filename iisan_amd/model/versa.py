@@ -72,7 +72,8 @@ class VersaIISANAdaptedMModel(nn.Module):
         tt = sample_items_text.reshape(-1, sample_items_text.shape[-2], a.text_embedding_dim).float().contiguous()   # model.py:402
         cfg = ops.make_versa_cfg(a.image_embedding_dim, a.text_embedding_dim, a.cv_adapter_down_size, a.embedding_dim, self.gated,
                                  a.adapter_activation == "GELU", self.remove_first, tc.shape[1], tt.shape[1],
-                                 self.side_cv_adapter_num_list, self.side_bert_adapter_num_list)
+                                 self.side_cv_adapter_num_list, self.side_bert_adapter_num_list,
+                                 taps_exact16=sample_items_images.dtype == torch.float16 and sample_items_text.dtype == torch.float16)
         item3 = ops.SideNetFn.apply(cfg, tc, tt, *self._abi_params(tc.device))
         E = a.embedding_dim
         return item3, (item3[:, :E], [item3[:, E:2 * E], item3[:, 2 * E:]])
@@ -83,17 +84,18 @@ class VersaIISANAdaptedMModel(nn.Module):
         pre = [0] if self.remove_first else []
         return pre + list(self.side_cv_adapter_num_list), pre + list(self.side_bert_adapter_num_list)
 
-    def forward_item3_packed(self, taps_cv_sel, taps_text_sel):
+    def forward_item3_packed(self, taps_cv_sel, taps_text_sel, exact16: bool = False):
         """Taps holding ONLY the layers each tower reads, in `packed_layers()` order (`iisan_amd.tapstore.TapStore.gather`):
         [M, n_img, D_i] and [M, n_text, D_t] instead of the reference's [.., 25, 1024] / [.., 81, 8192] files
-        (Code_Cached_Asym/data_utils/dataset.py:37-98)."""
+        (Code_Cached_Asym/data_utils/dataset.py:37-98).  `exact16`: both stores hold fp16 (the gathered fp32 values are exact
+        in fp16)."""
         a = self.args
         o = 1 if self.remove_first else 0
         ni, nt = len(self.side_cv_adapter_num_list), len(self.side_bert_adapter_num_list)
         assert taps_cv_sel.shape[1] == ni + o and taps_text_sel.shape[1] == nt + o, (taps_cv_sel.shape, taps_text_sel.shape)
         cfg = ops.make_versa_cfg(a.image_embedding_dim, a.text_embedding_dim, a.cv_adapter_down_size, a.embedding_dim, self.gated,
                                  a.adapter_activation == "GELU", self.remove_first, ni + o, nt + o,
-                                 list(range(o, ni + o)), list(range(o, nt + o)))
+                                 list(range(o, ni + o)), list(range(o, nt + o)), taps_exact16=exact16)
         item3 = ops.SideNetFn.apply(cfg, taps_cv_sel.float().contiguous(), taps_text_sel.float().contiguous(),
                                     *self._abi_params(taps_cv_sel.device))
         E = a.embedding_dim

@@ -105,10 +105,13 @@ def make_side_cfg(n_side: int, dim: int, down: int, emb: int, gated: bool, gelu:
 
 
 def make_versa_cfg(dim_cv: int, dim_text: int, down: int, emb: int, gated: bool, gelu: bool, remove_first: bool,
-                   tap_stride_cv: int, tap_stride_text: int, tap_index_cv: Sequence[int], tap_index_text: Sequence[int]):
-    """Asymmetric towers (Code_Cached_Asym): separate depth/width/tap lists per modality."""
+                   tap_stride_cv: int, tap_stride_text: int, tap_index_cv: Sequence[int], tap_index_text: Sequence[int],
+                   taps_exact16: bool = False):
+    """Asymmetric towers (Code_Cached_Asym): separate depth/width/tap lists per modality.  `taps_exact16`: the taps came from
+    fp16 storage (every value exact in fp16) — lets the dim-align products skip the tap's amax pass."""
     cfg = _lib.SideCfg()
     cfg.versa = 1
+    cfg.taps_exact16 = int(bool(taps_exact16))
     cfg.n_side, cfg.n_side_text = len(tap_index_cv), len(tap_index_text)
     cfg.dim_cv, cfg.dim_text, cfg.down, cfg.emb = dim_cv, dim_text, down, emb
     cfg.gated, cfg.gelu, cfg.remove_first = int(gated), int(gelu), int(remove_first)

@@ -140,6 +140,9 @@ typedef struct {
     int32_t n_side_text;      /* SANBs of the text tower                                                        */
     int32_t tap_index_text[IISAN_MAX_SIDE];
     int32_t first_index_text;
+    int32_t taps_exact16;     /* 1: the caller guarantees that every tap value is exactly representable in fp16 (taps cached in fp16, as
+                                 preprocess_*.py of Code_Cached_Asym writes them): the split-operand dim-align products then take the tap
+                                 with scale 1 and skip its amax pass.  0 = unknown (always safe)                            */
 } iisan_side_cfg;
 
 /* Parameter table (host array of device pointers), n_mm = min(n_cv, n_text):

@@ -665,6 +665,42 @@ def test_versa_at_baseline_config5_widths_matches_oracle(x3_mode):
     assert worst > 0.0
 
 
+def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(lib):
+    """fp16 tap stores make the model set `iisan_side_cfg.taps_exact16`: the dim-align products (8192 -> 1024, forward and weight
+    gradient) then take the tap with scale 1 and skip its amax pass.  Powers of two commute with fp32 rounding and the tap's lo
+    plane is zero either way, so the loss must equal bit for bit — and every gradient to 1e-6 of its scale (atomically combined sums aside) —
+    that of the same step on fp32 stores holding the same (fp16-rounded) values, where the scale comes from the amax pass."""
+    from iisan_amd import tapstore
+    n, bs = 600, 128
+    b = synth.scientific_batch(bs=bs, seed=43, item_num=n, res=2, words=2)
+    ids, lm = b.ids.view(-1).cuda(), b.log_mask.cuda()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    raw = [(torch.randn(n + 1, 7, d, generator=g, device="cuda") * 0.25).half() for d in (1024, 8192)]
+    lib.iisan_set_x3(2)               # every product whose shape allows it on the split-operand route (bs = 128: M = 1,408)
+    out = {}
+    try:
+        for store in ("fp16", "fp32"):
+            args = helpers.make_args(text_embedding_dim=8192, image_embedding_dim=1024, side_adapter_vit_list="3,7,11,15,19,23",
+                                     side_adapter_bert_list="4,19,34,49,64,79", image_layers=24, text_layers=80, drop_rate=0.0,
+                                     adapter_activation="GELU")
+            model = helpers.build_model(args, n, b.pop_prob, cached="versa")
+            shapes = {k: tuple(p.shape) for k, p in model.named_parameters() if p.requires_grad}
+            helpers.load_trainables(model, weights.fill_params_seeded(shapes, seed=556))
+            model.tap_stores = tuple(tapstore.TapStore(t.float(), range(7), "cuda", store) for t in raw)
+            model.train()
+            loss = model(ids, None, None, lm, None)
+            loss.backward()
+            out[store] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
+    finally:
+        lib.iisan_set_x3(1)
+    (l16, g16), (l32, g32) = out["fp16"], out["fp32"]
+    assert torch.equal(l16, l32), (l16.item(), l32.item())
+    for k in g16:
+        # (bias and gate gradients are column / scalar sums combined with atomics: their last bits move from run to run)
+        tol = 2e-3 if ("side_gate" in k or "user_encoder" in k) else 1e-6
+        assert (g16[k] - g32[k]).abs().max().item() <= tol * (g32[k].abs().max().item() + 1e-20), k
+
+
 @pytest.mark.parametrize("ce_fast", [1, 2, 0])
 def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
     """BASELINE config C3 (Cached, bs = 1024): logits [10240, 11264].  The fused loss and both gradients against the
