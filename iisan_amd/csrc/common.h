@@ -269,6 +269,10 @@ struct Gemm32Prob {
     int32_t amax_a_ready, amax_b_ready;
     uint32_t* x3_zeroed;   // gemm_x3 only: 12 words the caller has zeroed for this product alone (private amax, 1/scale, lo flags); null = zeroed here
 };
+// gate-fused dF product of the separate SANB launches (gemm32.hip: gemm32_k64_kernel<true, true>)
+struct K64Gate { const float* gate; const float* ga; const float* go; int64_t ldga, ldgo; float* dgate; int32_t scale_prev, store; float* d2; int64_t ldd2; int32_t d2_is_b; };
+bool gemm32_k64_gate_ok(const Gemm32Prob* probs, const K64Gate* gates, int nprob);
+int launch_gemm32_k64_gate(const Gemm32Prob* probs, const K64Gate* gates, int nprob, hipStream_t s);
 // Scratch for split-K of skinny long-K products that are NOT "+=" (their epilogue — bias, activation, masks — has to see the
 // complete sum, so the partial products meet in a buffer and a reducer applies it).  Registered by an executor for the
 // duration of its call (stream-ordered use; one host thread per process issues the work); null = never split.

@@ -478,12 +478,19 @@ __global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
 //               are then the columns 16 r + 4 g ..+3 of the block — contiguous over e.
 // Exact fp32 (v_mfma_f32_16x16x4_f32), fixed summation order.  In place (C == resid) is fine: a lane reads exactly the elements
 // it later writes.
-struct K64Prob { const float* A; const float* W; const float* bias; const float* resid; float* C; int64_t M; int32_t N, lda, ldw, ldc, ldr; };
+struct K64Prob {
+    const float* A; const float* W; const float* bias; const float* resid; float* C; int64_t M; int32_t N, lda, ldw, ldc, ldr;
+    // GATE variant (the dF product of a gated SANB step with the fusion's backward folded in, launch_gemm32_k64_gate):
+    //   dF = acc + resid;   dtheta += <dF, ga - go> g (1 - g) / 0.1   (go null: zeros);   C = dF * (scale_prev ? 1 - g : 1), if store
+    const float* gate; const float* ga; const float* go; int64_t ldga, ldgo; float* dgate; int32_t scale_prev, store;
+    float* d2; int64_t ldd2; int32_t d2_is_b;      // optional second output  d2 = (d2_is_b ? 1 - g : g) · dF  (Versa: gradient wrt the dim-aligned tap)
+};
 struct K64Batch { K64Prob p[4]; };
 
-template <bool TBV>
+template <bool TBV, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int nblk) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
+    __shared__ float gred[4];
     const K64Prob& p = batch.p[blockIdx.z];
     const int c0 = (int)blockIdx.y * nblk * 64;                     // first column of the slice
     if ((int64_t)blockIdx.x * 64 >= p.M || c0 >= p.N) return;       // block-uniform
@@ -516,6 +523,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int 
         }
     }
     const bool has_r = p.resid != nullptr, has_b = p.bias != nullptr;
+    float gpart = 0.f, gval = 0.f;
+    if constexpr (GATE) gval = 1.0f / (1.0f + __expf(-p.gate[0] / 0.1f));
+    const float cdp = (GATE && p.scale_prev) ? 1.f - gval : 1.f;
+    const float cgo = (GATE && p.go) ? 1.f : 0.f;
+    const float cd2 = GATE ? (p.d2_is_b ? 1.f - gval : gval) : 0.f;
     const float* wl = wlds + (TBV ? (16 * g) * stride + 4 * (4 * (j & 3) + (j >> 2)) : j * stride + 4 * g);
     __syncthreads();
     // ---- the workgroup's row tiles (64 rows each: wave w rows 16 w ..+15), the slice stays in LDS ------------------------------
@@ -536,6 +548,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int 
     // a missing residual / bias reads C / W instead and is discarded by a select: no branch between the loads
     const float* rrow = has_r ? p.resid + mrow * p.ldr + ocol : crow;
     const float* brow = has_b ? p.bias + ocol : p.W + 4 * g;
+    const float* garow = GATE ? p.ga + mrow * p.ldga + ocol : nullptr;
+    const float* gorow = GATE ? (p.go ? p.go + mrow * p.ldgo + ocol : p.ga + mrow * p.ldga + ocol) : nullptr;      // missing: read ga, weight 0
     f4 rn[4];                                                       // residual of the next block
 #pragma unroll
     for (int q = 0; q < 4; ++q) rn[q] = *(const f4*)(rrow + 16 * q);
@@ -559,6 +573,14 @@ __global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int 
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) rn[q] = *(const f4*)(rrow + 64 * tn + 16 * q);
+        f4 gav[4], gov[4];                                          // GATE: this block's fusion operands, consumed after the MFMAs
+        if constexpr (GATE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gav[q] = *(const f4*)(garow + 64 * t + 16 * q);
+                gov[q] = *(const f4*)(gorow + 64 * t + 16 * q);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         f4 acc[4];
 #pragma unroll
@@ -582,9 +604,25 @@ __global__ __launch_bounds__(256, 2) void gemm32_k64_kernel(K64Batch batch, int 
             // piece q = columns 64 t + 16 q + 4 g ..+3 of row j:  TBV: register q of the four fragments;  else fragment q
             const f4 v = TBV ? (f4){acc[0][q], acc[1][q], acc[2][q], acc[3][q]} : acc[q];
             const f4 z = {0.f, 0.f, 0.f, 0.f};
-            if (live) *(f4*)(crow + 64 * t + 16 * q) = v + ((has_b ? bv[q] : z) + (has_r ? rv[q] : z));
+            const f4 o = v + ((has_b ? bv[q] : z) + (has_r ? rv[q] : z));
+            if constexpr (GATE) {
+                if (live) {
+                    const f4 d = gav[q] - cgo * gov[q];
+                    gpart += (o[0] * d[0] + o[1] * d[1]) + (o[2] * d[2] + o[3] * d[3]);
+                    if (p.store) *(f4*)(crow + 64 * t + 16 * q) = o * cdp;
+                    if (p.d2) *(f4*)(p.d2 + mrow * p.ldd2 + ocol + 64 * t + 16 * q) = o * cd2;
+                }
+            } else {
+                if (live) *(f4*)(crow + 64 * t + 16 * q) = o;
+            }
         }
     }
+    }
+    if constexpr (GATE) {                       // one atomic per workgroup (same-address atomics serialise at ~12 ns)
+        gpart = wave_sum(gpart);
+        if (lane == 0) gred[wave] = gpart;
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.dgate, ((gred[0] + gred[1]) + (gred[2] + gred[3])) * gval * (1.f - gval) / 0.1f);
     }
 }
 
@@ -717,6 +755,59 @@ extern "C" void iisan_set_gemm32_k64(int32_t on) { g_use_k64 = on; }
 
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
 
+// Shapes the K = 64 kernel takes (shared by launch_gemm32's own dispatch test and the gate-fused entry below)
+static bool k64_shape_ok(const Gemm32Prob& q) {
+    return q.K == 64 && q.N >= 256 && (q.N & 63) == 0 && !q.act_src && q.ksplit_stride == 0 &&
+           (q.lda & 3) == 0 && (q.ldb & 3) == 0 && (q.ldc & 3) == 0 && (!q.resid || (q.ldr & 3) == 0) &&
+           (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.resid | (uintptr_t)q.bias) & 15) == 0;
+}
+static int g_use_k64_gate = 1;
+extern "C" void iisan_set_gemm32_k64_gate(int32_t on) { g_use_k64_gate = on; }
+bool gemm32_k64_gate_ok(const Gemm32Prob* probs, const K64Gate* gates, int nprob) {
+    if (!g_use_k64 || !g_use_k64_gate || nprob < 1 || nprob > 4) return false;
+    for (int i = 0; i < nprob; ++i) {
+        const K64Gate& g = gates[i];
+        if (!k64_shape_ok(probs[i]) || !probs[i].resid || !g.gate || !g.ga || !g.dgate || (g.ldga & 3) || (g.go && (g.ldgo & 3)) || (g.d2 && ((g.ldd2 & 3) || ((uintptr_t)g.d2 & 15))) ||
+            (((uintptr_t)g.ga | (uintptr_t)g.go) & 15))
+            return false;
+    }
+    return true;
+}
+// dF = A[M, 64] · W[64, N] + resid with the gated fusion's backward folded into the epilogue (sidenet.hip, separate SANB launches):
+// the gate gradient <dF, a - other> and the (1 - g) scaling of dprev happen while dF is in registers — fuse_bwd_kernel's pass
+// over dF (read + write of every [M, D] state gradient) disappears.  W stored [64, N] (G32_TB).
+int launch_gemm32_k64_gate(const Gemm32Prob* probs, const K64Gate* gates, int nprob, hipStream_t s) {
+    IISAN_CHECK_SHAPE(gemm32_k64_gate_ok(probs, gates, nprob), "gemm32_k64_gate: unsupported problem");
+    K64Batch kb{};
+    int64_t maxM = 0;
+    int maxnb = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const Gemm32Prob& q = probs[i];
+        K64Prob& k = kb.p[i];
+        k.A = q.A; k.W = q.B; k.bias = q.bias; k.resid = q.resid; k.C = q.C; k.M = q.M; k.N = q.N;
+        k.lda = q.lda; k.ldw = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr;
+        k.gate = gates[i].gate; k.ga = gates[i].ga; k.go = gates[i].go; k.ldga = gates[i].ldga; k.ldgo = gates[i].ldgo;
+        k.dgate = gates[i].dgate; k.scale_prev = gates[i].scale_prev; k.store = gates[i].store;
+        k.d2 = gates[i].d2; k.ldd2 = gates[i].ldd2; k.d2_is_b = gates[i].d2_is_b;
+        if (q.M > maxM) maxM = q.M;
+        if ((q.N >> 6) > maxnb) maxnb = q.N >> 6;
+    }
+    const int64_t rt = ceil_div(maxM, 64);
+    int nblk = 4;
+    while (nblk > 1 && rt * ceil_div(maxnb, nblk) * nprob < 1024) nblk >>= 1;
+    IISAN_CHECK_SHAPE(rt < (1ll << 31), "gemm32: grid too large");
+    const dim3 grid((unsigned)rt, (unsigned)ceil_div(maxnb, nblk), (unsigned)nprob);
+    const size_t lds = (size_t)64 * (64 * nblk + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm32_k64_kernel<true, true>), grid, dim3(256), lds, s, kb, nblk);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
     IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
     Gemm32Batch b{};
@@ -737,7 +828,9 @@ int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) 
             ok = q.K == 64 && q.N >= 256 && (q.N & 63) == 0 && !q.act_src && q.ksplit_stride == 0 &&
                  (q.lda & 3) == 0 && (q.ldb & 3) == 0 && (q.ldc & 3) == 0 && (!q.resid || (q.ldr & 3) == 0) &&
                  (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.resid | (uintptr_t)q.bias) & 15) == 0;
-            kb.p[i] = K64Prob{q.A, q.B, q.bias, q.resid, q.C, q.M, q.N, q.lda, q.ldb, q.ldc, q.ldr};
+            kb.p[i] = K64Prob{};
+            kb.p[i].A = q.A; kb.p[i].W = q.B; kb.p[i].bias = q.bias; kb.p[i].resid = q.resid; kb.p[i].C = q.C; kb.p[i].M = q.M; kb.p[i].N = q.N;
+            kb.p[i].lda = q.lda; kb.p[i].ldw = q.ldb; kb.p[i].ldc = q.ldc; kb.p[i].ldr = q.ldr;
             if (q.M > maxM) maxM = q.M;
             if ((q.N >> 6) > maxnb) maxnb = q.N >> 6;
         }

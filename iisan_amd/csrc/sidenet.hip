@@ -604,10 +604,33 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.dU[z], r, c.W(p.wd(z, k)), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], r, b.dO[z], p.D[z]);
         }
-        IISAN_TRY(launch_gemm32(pr, na, G32_TB, s));                              // dF = dO + dU · Wd (in place)
-
         const bool need_dp = sm.mm_i >= 0 && p.align;
-        if (cfg->gated || need_dp) {
+        // gated fusion: its backward rides in the epilogue of the dF product (gemm32_k64_kernel<true,
+        // true>: gate gradient and the (1 - g) scaling while dF is in registers) — no separate pass over dF
+        bool gate_folded = false;
+        if (cfg->gated) {
+            K64Gate kg[3];
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                FuseTower ft{};
+                c.fuse_operands(ft, z, k, sm);
+                kg[a] = K64Gate{};
+                kg[a].gate = ft.gate; kg[a].ga = ft.a; kg[a].ldga = ft.lda;
+                if (ft.type == 1) { kg[a].go = ft.b; kg[a].ldgo = ft.ldb; }
+                else { kg[a].go = ft.prev; kg[a].ldgo = ft.ldp; }
+                kg[a].dgate = G(p.gate(z, k));
+                kg[a].scale_prev = ft.type == 0 ? 1 : 0;
+                kg[a].store = k > 0 ? 1 : 0;          // block 0 starts from zeros / a tap: nobody reads that gradient
+                if (z == 2 && need_dp) { kg[a].d2 = b.dDP; kg[a].ldd2 = p.D[2]; kg[a].d2_is_b = p.text_wide ? 1 : 0; }      // gradient wrt the dim-aligned tap
+            }
+            if (gemm32_k64_gate_ok(pr, kg, na)) {
+                IISAN_TRY(launch_gemm32_k64_gate(pr, kg, na, s));                 // dprev = (1 - g | 1) · (dO + dU · Wd), dθ (in place)
+                gate_folded = true;
+            }
+        }
+        if (!gate_folded) IISAN_TRY(launch_gemm32(pr, na, G32_TB, s));            // dF = dO + dU · Wd (in place)
+
+        if (!gate_folded && (cfg->gated || need_dp)) {
             FuseArgs fa{};
             fa.M = M;
             int maxD = 0;

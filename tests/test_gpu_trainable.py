@@ -912,13 +912,14 @@ def test_cached_step_on_a_poisoned_heap_is_finite_and_its_weight_gradients_repro
             assert torch.equal(runs[0][k], runs[1][k]), k
 
 
-@pytest.mark.parametrize("route", ["x3", "sanb", "dw"])
+@pytest.mark.parametrize("route", ["x3", "sanb", "dw", "gate"])
 @pytest.mark.parametrize("versa", [False, True])
 def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route):
     """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128): the same step through
     (a) the split-operand fp16 GEMM forced onto every large Linear layer ("x3"), (b) the fused one-launch SANB step
     ("sanb", the product default where the towers' widths allow) and (c) the weight-gradient kernel (`gemm32_dw_kernel`, "dw":
-    product default, here against the tiled kernel on the otherwise plain route) against the plain route — separate fusion kernels and
+    product default, here against the tiled kernel on the otherwise plain route) and (d) the gated fusion's backward folded into the
+    dF product ("gate", product default on the separate launches, against `fuse_bwd_kernel`) against the plain route — separate fusion kernels and
     f32-matrix-core GEMMs, the path the small fixtures pin to the reference.  Loss within 2e-5, every gradient within 5e-4
     of its scale (2e-3 for the SASRec tensors: 1e-7 differences in the item embeddings flip single ReLU units of its
     feed-forward, seen as 1e-3 on `w_Q.weight` with either route).  GELU adapters: with ReLU a 1e-7 difference in a pre-activation
@@ -934,6 +935,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
         lib.iisan_set_x3(2 if (alt and route == "x3") else 0)
         lib.iisan_set_sanb_fused(2 if (alt and route == "sanb") else 0)
         lib.iisan_set_gemm32_dw(0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
+        lib.iisan_set_gemm32_k64_gate(0 if (route == "gate" and not alt) else 1)      # "gate": fusion backward folded into the dF product
         try:
             kw = dict(drop_rate=0.0, adapter_activation="GELU")
             if versa:
@@ -958,6 +960,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
             lib.iisan_set_x3(1)
             lib.iisan_set_sanb_fused(1)
             lib.iisan_set_gemm32_dw(1)
+            lib.iisan_set_gemm32_k64_gate(1)
     (l0, g0), (l1, g1) = out[False], out[True]
     assert abs(l1.item() - l0.item()) <= 2e-5 * abs(l0.item()), (l0.item(), l1.item())
     differ = 0
