@@ -101,6 +101,7 @@ EXTRA_SIGNATURES = {
     "iisan_set_gemm32_k64": (None, [i32]),
     "iisan_set_gemm32_dw": (None, [i32]),
     "iisan_set_gemm32_k64_gate": (None, [i32]),
+    "iisan_set_gemm32_n64f": (None, [i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),
 }

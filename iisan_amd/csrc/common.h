@@ -269,6 +269,18 @@ struct Gemm32Prob {
     int32_t amax_a_ready, amax_b_ready;
     uint32_t* x3_zeroed;   // gemm_x3 only: 12 words the caller has zeroed for this product alone (private amax, 1/scale, lo flags); null = zeroed here
 };
+// fusion-fed down projection of the separate SANB launches (gemm32.hip: gemm32_n64f_kernel):  F = fuse(a, b, prev) is formed in the
+// registers that feed the product, written out once, and  U = F·W^T + bias,  A = act(U)  leave together
+struct N64FDesc {
+    const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t type;   // as FuseTower (sidenet.hip)
+    float* F;                      // [M, K] (ld K)
+    const float* W; int32_t ldw;   // [64, K]
+    const float* bias;             // [64]
+    float* U; float* A;            // [M, 64]: pre-activation, activation
+    int64_t M; int32_t K;
+};
+bool gemm32_n64f_ok(const N64FDesc* d, int n);
+int launch_gemm32_n64f(const N64FDesc* d, int n, int gelu, hipStream_t s);
 // gate-fused dF product of the separate SANB launches (gemm32.hip: gemm32_k64_kernel<true, true>)
 struct K64Gate { const float* gate; const float* ga; const float* go; int64_t ldga, ldgo; float* dgate; int32_t scale_prev, store; float* d2; int64_t ldd2; int32_t d2_is_b; };
 bool gemm32_k64_gate_ok(const Gemm32Prob* probs, const K64Gate* gates, int nprob);

@@ -459,6 +459,119 @@ __global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
     }
 }
 
+// ---- fusion-fed down projection (separate SANB launches, forward) -----------------------------------------------------------
+//   F = fuse(a, b, prev)   (type 0: g·a + (1-g)·prev;  type 1: prev + g·a + (1-g)·b;  not gated: plain sums)      [M, K]
+//   U = F · W^T + bias,  A = act(U)                                                                                   [M, 64]
+// fuse_fwd_kernel wrote F and the down projection read it back; here a lane loads the 16-byte pieces of a / prev / b that make up ITS
+// piece of the MFMA operand (row j, k = k0 + 16 s + 4 g ..+3 — the contraction-index assignment of gemm32_k64_kernel, W [N, 64] case),
+// forms F in registers, stores it (the only copy that ever travels) and multiplies.  64 rows per workgroup (wave w rows 16 w ..+15),
+// the 64 x 64 weight tile through a double-buffered LDS image (one barrier per K-tile), all loads of the next K-tile requested one by
+// one among the MFMAs of the current one.  Split-K (blockIdx.y, a K range = a column range of F) writes raw partials for
+// gemm32_reduce_kernel, which applies bias / activation.
+struct N64FProb {
+    const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t type;
+    float* F; const float* W; int32_t ldw; const float* bias; float* U; float* A; float* P; int64_t pstride; int64_t M; int32_t K;
+};
+struct N64FBatch { N64FProb p[3]; int32_t gelu; };
+
+__global__ __launch_bounds__(256, 2) void gemm32_n64f_kernel(N64FBatch batch) {
+    __shared__ __attribute__((aligned(16))) float wl[2][64 * 68];
+    const N64FProb& p = batch.p[blockIdx.z];
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    if (m0 >= p.M) return;
+    const int ktiles = p.K >> 6;
+    const int per = (ktiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = (int)blockIdx.y * per;
+    int kt1 = kt0 + per;
+    if (kt1 > ktiles) kt1 = ktiles;
+    if (kt0 >= kt1) return;
+    const int nt = kt1 - kt0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t mj = m0 + 16 * wave + j;
+    const int64_t mrow = mj < p.M ? mj : p.M - 1;                   // rows past M compute row M-1 again and store nothing
+    const bool live = mj < p.M;
+    const bool gated = p.gate != nullptr;
+    const float gv = gated ? 1.0f / (1.0f + __expf(-p.gate[0] / 0.1f)) : 1.0f;
+    const float ca = gated ? gv : 1.f, cb = gated ? 1.f - gv : 1.f;
+    const bool has_b = p.type == 1;
+    const float cp = p.prev ? (p.type == 0 ? cb : 1.f) : 0.f;
+    // lane pieces: row mrow, floats k0 + 4 g + 16 s ..+3.  A missing prev / b reads `a` (weight 0 / never used): no branch between loads
+    const float* arow = p.a + mrow * p.lda + 4 * g;
+    const float* prow = p.prev ? p.prev + mrow * p.ldp + 4 * g : arow;
+    const float* brow = has_b ? p.b + mrow * p.ldb + 4 * g : arow;
+    float* frow = p.F + mrow * (int64_t)p.K + 4 * g;
+    // weight-tile staging: thread -> feature (tid >> 4) + 16 q, floats 4 (tid & 15) ..+3 of the K-tile
+    const float* wsrc = p.W + (int64_t)(tid >> 4) * p.ldw + (tid & 15) * 4;
+    const int64_t wq = (int64_t)16 * p.ldw;
+    const int sw = (tid >> 4) * 68 + (tid & 15) * 4;
+    f4 wst[4], an[4], pn[4], bn[4];
+    auto piece = [&](int t, int q) {                                 // one of the 16 loads of K-tile t (t past the end: the last again)
+        const int kk = (kt0 + (t < nt ? t : nt - 1)) * 64;
+        const int s = q & 3;
+        if (q < 4) an[s] = *(const f4*)(arow + kk + 16 * s);
+        else if (q < 8) pn[s] = *(const f4*)(prow + kk + 16 * s);
+        else if (q < 12) { if (has_b) bn[s] = *(const f4*)(brow + kk + 16 * s); }
+        else wst[s] = *(const f4*)(wsrc + kk + s * wq);
+    };
+#pragma unroll
+    for (int q = 0; q < 16; ++q) piece(0, q);
+    f4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int lw = j * 68 + 4 * g;
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        float* buf = wl[t & 1];
+        const int kk = (kt0 + t) * 64;
+        f4 xa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            *(f4*)(buf + sw + 16 * 68 * s) = wst[s];
+            f4 f = cp * pn[s] + ca * an[s];
+            if (has_b) f += cb * bn[s];
+            xa[s] = f;
+            if (live) *(f4*)(frow + kk + 16 * s) = f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        const float* wb = buf + lw;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f4 w[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) w[f] = *(const f4*)(wb + 16 * f * 68 + 16 * s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[f][e], xa[s][e], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                piece(t + 1, 4 * s + e);                            // 16 pieces, one after every 4th MFMA
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (!live) return;
+    // epilogue from the fragments: piece f = columns 16 f + 4 g ..+3 of row j
+    if (gridDim.y > 1) {
+        float* pr = p.P + (int64_t)blockIdx.y * p.pstride + mrow * 64 + 4 * g;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *(f4*)(pr + 16 * f) = acc[f];
+        return;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int n = 16 * f + 4 * g;
+        f4 v = acc[f] + *(const f4*)(p.bias + n);
+        *(f4*)(p.U + mrow * 64 + n) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = batch.gelu ? gelu_erf(v[e]) : fmaxf(v[e], 0.f);
+        *(f4*)(p.A + mrow * 64 + n) = v;
+    }
+}
+
 // ---- K = 64 products with a wide N: the up projection of a SANB and its dF product -------------------------------------------
 //   C[M, N] = A[M, 64] · op(W) (+ bias) (+ resid),   op(W): W stored [N, 64] (default) or [64, N] (TBV)
 // The tiled kernel above gives these ONE K-tile per workgroup — operand round trip, 64 MFMAs, epilogue, exit — with nothing in
@@ -754,6 +867,75 @@ extern "C" void iisan_set_gemm32_dw(int32_t on) { g_use_dw = on; }
 extern "C" void iisan_set_gemm32_k64(int32_t on) { g_use_k64 = on; }
 
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
+
+static int g_use_n64f = 1;
+extern "C" void iisan_set_gemm32_n64f(int32_t on) { g_use_n64f = on; }
+bool gemm32_n64f_ok(const N64FDesc* d, int n) {
+    if (!g_use_n64f || n < 1 || n > 3) return false;
+    for (int i = 0; i < n; ++i) {
+        const N64FDesc& q = d[i];
+        if (q.K < 256 || (q.K & 63) || (q.lda & 3) || (q.ldw & 3) || (q.prev && (q.ldp & 3)) || (q.type == 1 && (!q.b || (q.ldb & 3))) || !q.a || !q.bias ||
+            (((uintptr_t)q.a | (uintptr_t)q.b | (uintptr_t)q.prev | (uintptr_t)q.F | (uintptr_t)q.W | (uintptr_t)q.bias | (uintptr_t)q.U | (uintptr_t)q.A) & 15))
+            return false;
+    }
+    return true;
+}
+int launch_gemm32_n64f(const N64FDesc* d, int n, int gelu, hipStream_t s) {
+    IISAN_CHECK_SHAPE(gemm32_n64f_ok(d, n), "gemm32_n64f: unsupported problem");
+    N64FBatch nb{};
+    nb.gelu = gelu;
+    int64_t maxM = 0;
+    int max_k = 0;
+    for (int i = 0; i < n; ++i) {
+        N64FProb& q = nb.p[i];
+        q.a = d[i].a; q.b = d[i].b; q.prev = d[i].prev; q.lda = d[i].lda; q.ldb = d[i].ldb; q.ldp = d[i].ldp; q.gate = d[i].gate; q.type = d[i].type;
+        q.F = d[i].F; q.W = d[i].W; q.ldw = d[i].ldw; q.bias = d[i].bias; q.U = d[i].U; q.A = d[i].A; q.M = d[i].M; q.K = d[i].K;
+        if (d[i].M > maxM) maxM = d[i].M;
+        if (d[i].K > max_k) max_k = d[i].K;
+    }
+    const int64_t rt = ceil_div(maxM, 64);
+    IISAN_CHECK_SHAPE(rt < (1ll << 31), "gemm32: grid too large");
+    int ks = 1;
+    if (g_scratch && rt * n < 384) {           // too few 64-row tiles to fill the chip: split K through the executor's scratch
+        ks = max_k / (4 * TK);
+        if (ks > 16) ks = 16;
+        while (ks >= 2) {
+            int64_t need = 0;
+            for (int i = 0; i < n; ++i) need += (int64_t)ks * (int64_t)align_up((size_t)(d[i].M * 64), 64);
+            if ((size_t)need <= g_scratch_floats) break;
+            ks >>= 1;
+        }
+        if (ks < 2) ks = 1;
+    }
+    if (ks >= 2) {
+        int64_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            nb.p[i].P = g_scratch + off;
+            nb.p[i].pstride = (int64_t)align_up((size_t)(d[i].M * 64), 64);
+            off += ks * nb.p[i].pstride;
+        }
+    }
+    hipLaunchKernelGGL(gemm32_n64f_kernel, dim3((unsigned)rt, (unsigned)ks, (unsigned)n), dim3(256), 0, s, nb);
+    IISAN_LAUNCH_OK();
+    if (ks < 2) return IISAN_OK;
+    ReduceBatch rb{};
+    int64_t max_mn = 0;
+    for (int i = 0; i < n; ++i) {
+        Gemm32Prob q{};
+        q.C = d[i].A; q.ldc = 64; q.bias = d[i].bias; q.act_src = d[i].U; q.M = d[i].M; q.N = 64; q.K = d[i].K; q.ldr = 64;
+        rb.p[i] = q;
+        rb.P[i] = nb.p[i].P;
+        rb.stride[i] = nb.p[i].pstride;
+        const int64_t ktiles = d[i].K / TK, per = ceil_div(ktiles, (int64_t)ks);
+        rb.ns[i] = (int32_t)ceil_div(ktiles, per);
+        if (d[i].M * 64 > max_mn) max_mn = d[i].M * 64;
+    }
+    int64_t blocks = ceil_div(max_mn, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, rb, ks, (gelu ? G32_GELU : G32_RELU) | G32_PREACT);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
 
 // Shapes the K = 64 kernel takes (shared by launch_gemm32's own dispatch test and the gate-fused entry below)
 static bool k64_shape_ok(const Gemm32Prob& q) {

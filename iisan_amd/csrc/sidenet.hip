@@ -474,14 +474,35 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             fa.t[a].F = b.F[sm.k[a]][sm.z[a]];
             if (p.D[sm.z[a]] > maxD) maxD = p.D[sm.z[a]];
         }
-        hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid(M, maxD), sm.nact), dim3(256), 0, s, fa);
-        IISAN_LAUNCH_OK();
         Gemm32Prob pr[3];
-        for (int a = 0; a < sm.nact; ++a) {   // U = F Wd^T + bd (saved), A = act(U)
-            const int z = sm.z[a], k = sm.k[a];
-            pr[a] = prob(b.F[k][z], p.D[z], c.W(p.wd(z, k)), p.D[z], c.W(p.wd(z, k) + 1), b.A[k][z], p.r, M, p.r, p.D[z], nullptr, 0, b.U[k][z]);
+        // fusion + down projection + activation in one launch where the shapes allow (gemm32_n64f_kernel: F is formed in the
+        // registers that feed the product and written once); else the fusion kernel, then the product
+        bool fed = false;
+        if (p.r == 64) {
+            N64FDesc nd[3];
+            for (int a = 0; a < sm.nact; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                const FuseTower& ft = fa.t[a];
+                nd[a] = N64FDesc{};
+                nd[a].a = ft.a; nd[a].b = ft.b; nd[a].prev = ft.prev; nd[a].lda = ft.lda; nd[a].ldb = ft.ldb; nd[a].ldp = ft.ldp;
+                nd[a].gate = ft.gate; nd[a].type = ft.type;
+                nd[a].F = b.F[k][z]; nd[a].W = c.W(p.wd(z, k)); nd[a].ldw = p.D[z]; nd[a].bias = c.W(p.wd(z, k) + 1);
+                nd[a].U = b.U[k][z]; nd[a].A = b.A[k][z]; nd[a].M = M; nd[a].K = p.D[z];
+            }
+            if (gemm32_n64f_ok(nd, sm.nact)) {
+                IISAN_TRY(launch_gemm32_n64f(nd, sm.nact, cfg->gelu, s));
+                fed = true;
+            }
         }
-        IISAN_TRY(launch_gemm32(pr, sm.nact, act_flag | G32_PREACT, s));
+        if (!fed) {
+            hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid(M, maxD), sm.nact), dim3(256), 0, s, fa);
+            IISAN_LAUNCH_OK();
+            for (int a = 0; a < sm.nact; ++a) {   // U = F Wd^T + bd (saved), A = act(U)
+                const int z = sm.z[a], k = sm.k[a];
+                pr[a] = prob(b.F[k][z], p.D[z], c.W(p.wd(z, k)), p.D[z], c.W(p.wd(z, k) + 1), b.A[k][z], p.r, M, p.r, p.D[z], nullptr, 0, b.U[k][z]);
+            }
+            IISAN_TRY(launch_gemm32(pr, sm.nact, act_flag | G32_PREACT, s));
+        }
         for (int a = 0; a < sm.nact; ++a) {   // state = A Wu^T + bu + F
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.A[k][z], p.r, c.W(p.wd(z, k) + 2), p.r, c.W(p.wd(z, k) + 3), b.O[k][z], p.D[z], M, p.D[z], p.r, b.F[k][z], p.D[z]);

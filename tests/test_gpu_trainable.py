@@ -912,7 +912,7 @@ def test_cached_step_on_a_poisoned_heap_is_finite_and_its_weight_gradients_repro
             assert torch.equal(runs[0][k], runs[1][k]), k
 
 
-@pytest.mark.parametrize("route", ["x3", "sanb", "dw", "gate"])
+@pytest.mark.parametrize("route", ["x3", "sanb", "dw", "gate", "n64f"])
 @pytest.mark.parametrize("versa", [False, True])
 def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route):
     """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128): the same step through
@@ -936,6 +936,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
         lib.iisan_set_sanb_fused(2 if (alt and route == "sanb") else 0)
         lib.iisan_set_gemm32_dw(0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
         lib.iisan_set_gemm32_k64_gate(0 if (route == "gate" and not alt) else 1)      # "gate": fusion backward folded into the dF product
+        lib.iisan_set_gemm32_n64f(0 if (route == "n64f" and not alt) else 1)          # "n64f": fusion folded into the down projection
         try:
             kw = dict(drop_rate=0.0, adapter_activation="GELU")
             if versa:
@@ -961,6 +962,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
             lib.iisan_set_sanb_fused(1)
             lib.iisan_set_gemm32_dw(1)
             lib.iisan_set_gemm32_k64_gate(1)
+            lib.iisan_set_gemm32_n64f(1)
     (l0, g0), (l1, g1) = out[False], out[True]
     assert abs(l1.item() - l0.item()) <= 2e-5 * abs(l0.item()), (l0.item(), l1.item())
     differ = 0

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the gate-folded dF product (iisan_set_gemm32_k64_gate 1) against dF product + fuse_bwd_kernel (0) on the Cached step
+"""A/B of a 0/1 route knob of the library (default: the gate-folded dF product, iisan_set_gemm32_k64_gate; `python tools/gate_ab.py
+gemm32_n64f` for the fusion-fed down projection) on the Cached step
 (bs = 1024), all slots and distinct ids, and on the Versa step; one process, interleaved rounds."""
 import contextlib
 import io
@@ -14,6 +15,7 @@ from iisan_amd import _lib  # noqa: E402
 lib = _lib.load()
 import torch  # noqa: E402
 
+KNOB = "iisan_set_" + (sys.argv[1] if len(sys.argv) > 1 else "gemm32_k64_gate")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 
@@ -28,6 +30,6 @@ def run(extra, steps=20):
 for name, extra in (("cached", ["fp32"]), ("dedup ", ["fp32", "--dedup"]), ("versa ", ["fp16", "--versa"])):
     for rnd in range(3):
         for mode in (0, 1):
-            lib.iisan_set_gemm32_k64_gate(mode)
-            print(f"{name} round {rnd} gate-folded={mode}: {run(extra):.3f} ms/step", flush=True)
-lib.iisan_set_gemm32_k64_gate(1)
+            getattr(lib, KNOB)(mode)
+            print(f"{name} round {rnd} {KNOB[10:]}={mode}: {run(extra):.3f} ms/step", flush=True)
+getattr(lib, KNOB)(1)
