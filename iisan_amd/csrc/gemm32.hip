@@ -472,12 +472,12 @@ struct N64FProb {
     const float* a; const float* b; const float* prev; int64_t lda, ldb, ldp; const float* gate; int32_t type;
     float* F; const float* W; int32_t ldw; const float* bias; float* U; float* A; float* P; int64_t pstride; int64_t M; int32_t K;
 };
-struct N64FBatch { N64FProb p[3]; int32_t gelu; };
+struct N64FBatch { N64FProb p[3]; int32_t gelu; int32_t rpw; };      // rpw: rows per workgroup (<= 64; waves whose 16 rows start past it only stage)
 
 __global__ __launch_bounds__(256, 2) void gemm32_n64f_kernel(N64FBatch batch) {
     __shared__ __attribute__((aligned(16))) float wl[2][64 * 68];
     const N64FProb& p = batch.p[blockIdx.z];
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int64_t m0 = (int64_t)blockIdx.x * batch.rpw;
     if (m0 >= p.M) return;
     const int ktiles = p.K >> 6;
     const int per = (ktiles + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_n64f_kernel(N64FBatch batch) {
     const int j = lane & 15, g = lane >> 4;
     const int64_t mj = m0 + 16 * wave + j;
     const int64_t mrow = mj < p.M ? mj : p.M - 1;                   // rows past M compute row M-1 again and store nothing
-    const bool live = mj < p.M;
+    const bool live = mj < p.M && 16 * wave + j < batch.rpw;
+    const bool wave_on = 16 * wave < batch.rpw;                     // (wave-uniform) a wave past the tile only helps staging the weights
     const bool gated = p.gate != nullptr;
     const float gv = gated ? 1.0f / (1.0f + __expf(-p.gate[0] / 0.1f)) : 1.0f;
     const float ca = gated ? gv : 1.f, cb = gated ? 1.f - gv : 1.f;
@@ -538,19 +539,24 @@ __global__ __launch_bounds__(256, 2) void gemm32_n64f_kernel(N64FBatch batch) {
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         const float* wb = buf + lw;
+        if (wave_on) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f4 w[4];
+            for (int s = 0; s < 4; ++s) {
+                f4 w[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) w[f] = *(const f4*)(wb + 16 * f * 68 + 16 * s);
+                for (int f = 0; f < 4; ++f) w[f] = *(const f4*)(wb + 16 * f * 68 + 16 * s);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[f][e], xa[s][e], acc[f], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                piece(t + 1, 4 * s + e);                            // 16 pieces, one after every 4th MFMA
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[f][e], xa[s][e], acc[f], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(t + 1, 4 * s + e);                        // 16 pieces, one after every 4th MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        } else {
+#pragma unroll
+            for (int q = 12; q < 16; ++q) piece(t + 1, q);          // its share of the next weight tile
         }
     }
     if (!live) return;
@@ -893,7 +899,16 @@ int launch_gemm32_n64f(const N64FDesc* d, int n, int gelu, hipStream_t s) {
         if (d[i].M > maxM) maxM = d[i].M;
         if (d[i].K > max_k) max_k = d[i].K;
     }
-    const int64_t rt = ceil_div(maxM, 64);
+    // rows per workgroup: 64, or — when the rows divide into one workgroup per CU and tower with 33..63 rows each (Cached,
+    // bs = 1024: 11,264 = 256 x 44) — that count: 768 workgroups = exactly three per CU instead of 528 = 2.06 (same box: 5.72 ->
+    // 5.63 ms per Cached step; knob value 2 = always 64).  The same tiling made gemm32_k64_kernel SLOWER (44 rows x 3 blocks: 5.79
+    // against 5.62 ms): there the fourth wave's idle MFMA share and the extra weight staging outweigh the balance.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int rpw = 64;
+    if (g_use_n64f != 2 && maxM % cus == 0 && maxM / cus > 32 && maxM / cus < 64) rpw = (int)(maxM / cus);
+    nb.rpw = rpw;
+    const int64_t rt = ceil_div(maxM, rpw);
     IISAN_CHECK_SHAPE(rt < (1ll << 31), "gemm32: grid too large");
     int ks = 1;
     if (g_scratch && rt * n < 384) {           // too few 64-row tiles to fill the chip: split K through the executor's scratch
