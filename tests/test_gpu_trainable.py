@@ -668,7 +668,7 @@ def test_versa_at_baseline_config5_widths_matches_oracle(x3_mode):
 def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(lib):
     """fp16 tap stores make the model set `iisan_side_cfg.taps_exact16`: the dim-align products (8192 -> 1024, forward and weight
     gradient) then take the tap with scale 1 and skip its amax pass.  Powers of two commute with fp32 rounding and the tap's lo
-    plane is zero either way, so the loss must equal bit for bit — and every gradient to 1e-6 of its scale (atomically combined sums aside) —
+    plane is zero either way, so the loss must equal bit for bit — and every gradient to 1e-5 of its scale (atomically combined sums aside) —
     that of the same step on fp32 stores holding the same (fp16-rounded) values, where the scale comes from the amax pass."""
     from iisan_amd import tapstore
     n, bs = 600, 128
@@ -697,7 +697,7 @@ def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(l
     assert torch.equal(l16, l32), (l16.item(), l32.item())
     for k in g16:
         # (bias and gate gradients are column / scalar sums combined with atomics: their last bits move from run to run)
-        tol = 2e-3 if ("side_gate" in k or "user_encoder" in k) else 1e-6
+        tol = 2e-3 if ("side_gate" in k or "user_encoder" in k) else 1e-5
         assert (g16[k] - g32[k]).abs().max().item() <= tol * (g32[k].abs().max().item() + 1e-20), k
 
 
