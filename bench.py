@@ -6,7 +6,8 @@ synthetic batches, bs=128 sequences per GPU (1408 item slots per step per GPU), 
 One "step" = zero_grad -> frozen ViT+BERT forward with CLS taps (HIP, fp16 MFMA operands / fp32 accumulate) ->
 side network -> com_dense -> SASRec -> fused in-batch CE -> backward -> (N>1: one RCCL all-reduce of the flat
 gradient buffer) -> fused Adam.  Inputs are resident in HBM before the timed region.  ALL 1408 slots are encoded
-(padding slots included, like the reference); no dedup, no pruning.
+(padding slots included, like the reference) and EVERY encoder block runs on EVERY token (as HF does; SURVEY 8d's
+clean configuration): no dedup, no pruning.  The two legal work-pruning options are separate `secondary` lines.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --gpus 8 --steps 10 --warmup 3          # starts its own 8 ranks (torch.distributed.run) when none exist
@@ -14,8 +15,8 @@ gradient buffer) -> fused Adam.  Inputs are resident in HBM before the timed reg
         bench.py --gpus N --steps K --warmup W
 
 The default single-GPU run prints ONE JSON line: the headline plus `secondary` — the other BASELINE configurations and
-ablations timed in the same process (each a few seconds): every encoder block on every token (`--full-blocks`, the
-SURVEY §8d-clean figure), bf16 encoder operands, Code_Cached at bs=1024 (config 3) and IISAN-Versa shapes (config 5).
+ablations timed in the same process (each a few seconds): the CLS-only last block (`--cls-prune`, work pruning), bf16
+encoder operands, Code_Cached at bs=1024 (config 3), IISAN-Versa shapes (config 5) and the eval path (users/s).
 """
 import argparse
 import ctypes as C
@@ -35,12 +36,13 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SLOT = 40.28e9          # ViT 35.126 + BERT 5.129 fwd + side net 3x0.008 (fwd+bwd)
 MFMA_PEAK = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK = 8.0e12                # HBM3E spec (MI355X_MICROARCH.md; 6.3e12 achievable)
+F32_MFMA_PEAK = 157.3e12         # v_mfma_f32_*_f32 dense peak (cdna_hip_programming.md, gfx950 header line)
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bs", type=int, default=None, help="sequences per GPU (default 128; 1024 with --cached, 128 with --versa)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type of the frozen encoders")
@@ -65,12 +67,18 @@ def parse(argv=None):
     ap.add_argument("--x3", type=int, default=1, choices=[0, 1, 2],
                     help="route of the side network's large Linear layers: 1 = product default, 0 = f32 matrix cores only, "
                          "2 = split-operand fp16 GEMM wherever the shape allows (A/B knob)")
-    ap.add_argument("--full-blocks", action="store_true",
-                    help="ablation: run every encoder block on every token like HF does (default: the last block computes "
-                         "attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed; same taps)")
+    ap.add_argument("--cls-prune", action="store_true",
+                    help="work pruning, reported separately (SURVEY 8d): the last executed encoder block computes K/V for all "
+                         "tokens but attention/O/MLP for the CLS rows only, since only hidden_states[i][:,0] is consumed (same "
+                         "taps).  Default: every block on every token, as HF does")
+    ap.add_argument("--full-blocks", action="store_true", help="(the default since round 3; accepted for old command lines)")
+    ap.add_argument("--eval", action="store_true",
+                    help="secondary workload (SURVEY 8f-2, never the headline): the eval path at Scientific size — users/s of "
+                         "evaluate_ranks end to end, of iisan_score_rank alone, and items/s of item_table from cached taps")
     a = ap.parse_args(argv)
     if a.bs is None:
         a.bs = 128 if (a.versa or not a.cached) else 1024
+    a.full_blocks = not a.cls_prune
     return a
 
 
@@ -98,12 +106,13 @@ class Clock:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, step, warmup, steps, lib=None, timed=False):
+    def run(self, step, warmup, steps, lib=None, timed=False, cls=1):
+        """`timed`: HIP events around every launch of kernel family `cls` (1 = gemm16, 2 = the gemm32.hip family) on its stream."""
         for _ in range(warmup):
             out = step()
         self.sync()
         if lib is not None:
-            lib.iisan_timing_enable(1 if timed else 0)
+            lib.iisan_timing_enable(cls if timed else 0)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
@@ -121,6 +130,18 @@ class Clock:
 # ---------------------------------------------------------------------------------------------------------------
 # Cached / Versa (BASELINE configs 3 and 5)
 # ---------------------------------------------------------------------------------------------------------------
+
+def cached_pmc_traffic(a):
+    """HBM-side bytes of one whole Cached / Versa step (all kernels) from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic_cached.json, written by tools/pmc_traffic.py --step); null unless this run is that configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_cached.json")
+    if not os.path.exists(path) or a.dedup:
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    key = f"{'versa' if a.versa else 'cached'}_{a.cached}_bs{a.bs}"
+    return float(d[key]["bytes_per_step"]) if key in d else None
+
 
 def cached_line(a, lib, dev, rank, world, steps, warmup):
     """Code_Cached IISAN (side network + SASRec + in-batch CE + Adam, fwd+bwd) on taps gathered on the device from a packed
@@ -160,6 +181,13 @@ def cached_line(a, lib, dev, rank, world, steps, warmup):
     elapsed, loss = Clock(dev, world).run(lambda: tr.step(ids, None, None, log_mask), warmup, steps)
     if not torch.isfinite(loss).item():
         raise SystemExit("bench.py: cached loss is not finite")
+    # second pass of the same steps with HIP events around every launch of the dominant kernel family (two event records per
+    # launch on a ~100-launch, ~5 ms step are not free: `value` comes from the pass above, without them)
+    Clock(dev, world).run(lambda: tr.step(ids, None, None, log_mask), 0, steps, lib, timed=rank == 0, cls=2)
+    ms, fl = C.c_double(0), C.c_double(0)
+    n_launch = lib.iisan_timing_collect(C.byref(ms), C.byref(fl)) if rank == 0 else 0
+    fam_bytes = lib.iisan_timing_last_bytes()
+    fam_tf = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     slots = a.bs * 11
     distinct = int(torch.unique(ids).numel())
     value = slots * world * steps / elapsed
@@ -174,8 +202,98 @@ def cached_line(a, lib, dev, rank, world, steps, warmup):
                                f"{(st[0].nbytes() + st[1].nbytes()) / 1e6:.0f} MB in HBM",
                    "loss": float(loss.item())},
         "roofline": {"bound": "hbm", "achieved": value / world * alg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": value / world * alg / HBM_PEAK, "traffic": None,
-                     "note": f"whole step against the algorithmic {alg:.0f} B/slot of SURVEY 8d (tap reads only)"},
+                     "frac": value / world * alg / HBM_PEAK,
+                     # HBM-side bytes of one WHOLE step from the committed PMC passes of this configuration (null for others)
+                     "traffic": cached_pmc_traffic(a), "traffic_algorithmic": alg * slots,
+                     "note": f"whole step against the algorithmic {alg:.0f} B/slot of SURVEY 8d (tap reads only)",
+                     # what the step is actually bound by: the f32-matrix-core GEMM family of gemm32.hip (SANB products, weight
+                     # gradients, heads; HIP events around every launch of the family on its stream inside the timed region)
+                     "dominant_kernels": {"kernel": "gemm32.hip family (gemm32_kernel / gemm32_k64_kernel / gemm32_n64f_kernel / "
+                                                    "gemm32_dw_kernel + split-K reducers)", "bound": "mfma (f32 inputs)",
+                                          "launches": int(n_launch), "launches_per_step": n_launch / max(steps, 1),
+                                          "avg_launch_ms": ms.value / max(n_launch, 1), "ms_per_step": ms.value / max(steps, 1),
+                                          "flop_per_step": fl.value / max(steps, 1), "achieved": fam_tf, "peak": F32_MFMA_PEAK / 1e12,
+                                          "unit": "TFLOP/s", "frac": fam_tf * 1e12 / F32_MFMA_PEAK,
+                                          "operand_bytes_per_step": fam_bytes / max(steps, 1)}},
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Eval path (reference: Code_Uncached/data_utils/metrics.py:59-67,69-107,157-246) — secondary line
+# ---------------------------------------------------------------------------------------------------------------
+
+SCI_USERS = 12076                # users of Amazon-Scientific after filtering
+
+
+def eval_line(a, lib, dev, rank, world, reps=5):
+    """The path that produces HR@10 at Scientific size: item table [20,315 x 64] from cached taps (`item_table`), then for
+    12,076 users SASRec -> scores against every item -> history mask -> exact rank of the target (`evaluate_ranks`:
+    host packing of the user sequences included; and its rank kernel `iisan_score_rank` alone, timed with HIP events on the
+    launching stream).  Roofline of the rank kernel: the score product [U, 64] x [64, N] on the f32 matrix cores (2*U*N*64
+    FLOP; its memory side is the 5.2 MB table + 3.1 MB of user vectors — the [U, N] scores are never materialised)."""
+    import numpy as np
+    from iisan_amd import evaluate, factory, ops, synth
+    n, U = synth.SCI_ITEM_NUM, SCI_USERS
+    args = factory.make_args()
+    model = factory.build_model(args, n, synth.make_pop_prob(n), cached=True, device=dev)
+    model.eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    tc = torch.randn(n + 1, 13, 768, generator=g, device=dev).mul_(0.25)      # the reference's [N, 13, 768] fp32 layout
+    tt = torch.randn(n + 1, 13, 768, generator=g, device=dev).mul_(0.25)
+
+    def wall(fn, warm=1):
+        for _ in range(warm):
+            out = fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], out
+
+    t_tab, table = wall(lambda: evaluate.item_table(model, tc, tt, batch=2048, rank=rank, world=world))
+    rs = np.random.RandomState(11 + rank)
+    ls = np.array(sorted(synth.SCI_LEN_HIST))
+    pr = np.array([synth.SCI_LEN_HIST[int(l)] for l in ls], dtype=np.float64)
+    lens = rs.choice(ls, size=U, p=pr / pr.sum())
+    seqs = [rs.choice(np.arange(1, n + 1), size=int(l), replace=False).tolist() for l in lens]
+    hists = [s_[:-1] for s_ in seqs]
+    t_e2e, ranks = wall(lambda: evaluate.evaluate_ranks(model, table, seqs, hists, max_seq_len=10, batch=4096, rank=rank, world=world))
+    hit, ndcg = evaluate.hit_ndcg(ranks)
+    # the rank kernel alone: one launch over all users, HIP events on torch's current stream (= the stream ops.score_rank
+    # hands to the ABI)
+    prec = torch.randn(U, 64, generator=g, device=dev)
+    hist = torch.zeros(U, 10, dtype=torch.int32, device=dev)
+    tgt = torch.randint(1, n + 1, (U,), generator=g, device=dev, dtype=torch.int32)
+    for _ in range(2):
+        ops.score_rank(prec, table, hist, tgt)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for e0, e1 in ev:
+        e0.record()
+        ops.score_rank(prec, table, hist, tgt)
+        e1.record()
+    torch.cuda.synchronize()
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
+    flops = 2.0 * U * n * 64
+    return {
+        "metric": "users/s, eval path (SASRec + scores against every item + history mask + exact target rank), Scientific size",
+        "value": U * world / t_e2e, "unit": "users/s", "n_gpus": world, "steps": reps, "warmup": 1,
+        "ms_per_step": t_e2e * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"evaluate_ranks end to end (host packing of {U} user sequences included), item table "
+                               f"[{n + 1}, 64], histories <= 10, user batch 4096",
+                   "hit10": hit, "ndcg10": ndcg,
+                   "item_table": {"items_per_s": (n + 1) / t_tab, "ms": t_tab * 1e3,
+                                  "what": f"item_table: side network + com_dense forward over {n + 1} items from cached taps "
+                                          "[N, 13, 768] fp32 x 2 (reference layout), item batch 2048"},
+                   "score_rank_alone": {"users_per_s": U / (ms * 1e-3), "ms_per_launch": ms, "launch": f"{U} users x {n + 1} items"}},
+        "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": flops / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": None, "kernel": "score_rank_kernel",
+                     "launches": len(ev), "avg_launch_ms": ms, "flop_per_launch": flops,
+                     "traffic_algorithmic": float((n + 1) * 64 * 4 + U * 64 * 4 + U * 10 * 4 + U * 8)},
     }
 
 
@@ -187,13 +305,15 @@ def pmc_traffic(a):
     """Measured memory-side bytes per gemm16 launch of the DEFAULT configuration, from the committed summary of the two PMC
     passes (tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run, so any other configuration
     reports null."""
-    default = (a.bs == 128 and a.dtype == "fp16" and not a.full_blocks and not a.dedup and not a.overlap_towers
+    default = (a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup and not a.overlap_towers
                and not a.cached and a.chunk == 0)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not default or not os.path.exists(path):
         return None
     with open(path) as f:
-        return float(json.load(f)["avg_bytes_per_launch"])
+        d = json.load(f)
+    # the committed passes must be of THIS default (round 3 flipped it to every block on every token)
+    return float(d["avg_bytes_per_launch"]) if d.get("encoder_blocks") == "all tokens in every block" else None
 
 
 class Uncached:
@@ -237,6 +357,7 @@ class Uncached:
         enc = self.model.mm_encoder
         need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
         self.model.eval()
+        self.lib.iisan_set_full_blocks(1 if self.a.full_blocks else 0)
         try:
             with torch.no_grad():
                 for v in (0, 1):
@@ -245,6 +366,7 @@ class Uncached:
                     taps[v] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
         finally:
             self.lib.iisan_set_gemm16_variant(0)
+            self.lib.iisan_set_full_blocks(0)
             self.model.train()
         rel = abs(loss[0] - loss[1]) / abs(loss[1])
         tap_rel = 0.0
@@ -257,7 +379,29 @@ class Uncached:
                              f"worst tap layer rel {tap_rel:.2e}")
         return {"loss_auto_dispatch": loss[0], "loss_v1_kernels": loss[1], "loss_rel": rel, "worst_tap_layer_rel": tap_rel}
 
-    def line(self, steps, warmup, dtype="fp16", full_blocks=False, headline=True, overlap=None):
+    def dist_info(self, steps):
+        """What a multi-rank line actually ran on: backend, world size, every rank's device, and the
+        device time of the one data-path collective per step.  Two ranks on one device under backend nccl (RCCL) would be a
+        mis-launch: refuse to print a line for it."""
+        p = torch.cuda.get_device_properties(self.dev)
+        mine = {"rank": self.rank, "host": socket.gethostname(), "device": self.dev.index, "name": p.name,
+                "uuid": str(getattr(p, "uuid", "")), "pci_bus_id": getattr(p, "pci_bus_id", None)}
+        n_ar, ar_ms = self.tr.allreduce_ms()
+        mine["allreduce_ms_per_step"] = ar_ms / max(n_ar, 1)
+        every = [None] * self.world
+        dist.all_gather_object(every, mine)
+        backend = dist.get_backend()
+        keys = [(d["host"], d["uuid"] or d["device"]) for d in every]
+        if backend == "nccl" and len(set(keys)) != self.world:
+            raise SystemExit(f"bench.py: backend nccl (RCCL) with two ranks on one device: {every}")
+        return {"backend": backend, "world": dist.get_world_size(), "devices": [d["device"] for d in every],
+                "device_uuids": [d["uuid"] for d in every], "hosts": sorted(set(d["host"] for d in every)),
+                "collective": f"one SUM all-reduce of the flat gradient buffer per step ({self.tr.grad.numel() * 4 / 1e6:.2f} MB fp32)",
+                "allreduces_timed": n_ar, "steps_timed": steps,
+                "allreduce_ms_per_step": [round(d["allreduce_ms_per_step"], 4) for d in every],
+                "allreduce_ms_per_step_max": max(d["allreduce_ms_per_step"] for d in every)}
+
+    def line(self, steps, warmup, dtype="fp16", full_blocks=True, headline=True, overlap=None):
         a, lib, world = self.a, self.lib, self.world
         self.set_dtype(dtype)
         lib.iisan_set_full_blocks(1 if full_blocks else 0)
@@ -265,11 +409,22 @@ class Uncached:
         prev_overlap = enc.overlap_towers
         if overlap is not None:
             enc.overlap_towers = overlap
+        clock = Clock(self.dev, world)
         try:
-            elapsed, loss = Clock(self.dev, world).run(self.step, warmup, steps, lib, timed=self.rank == 0)
+            if world > 1:                       # warm-up outside the all-reduce timing, then HIP events around every collective
+                for _ in range(warmup):
+                    self.step()
+                self.tr.time_allreduce = True
+                self.tr.allreduce_ms()
+                elapsed, loss = clock.run(self.step, 0, steps, lib, timed=self.rank == 0)
+                self.tr.time_allreduce = False
+            else:
+                elapsed, loss = clock.run(self.step, warmup, steps, lib, timed=self.rank == 0)
         finally:
             lib.iisan_set_full_blocks(0)
             enc.overlap_towers = prev_overlap
+            self.tr.time_allreduce = False
+        dinfo = self.dist_info(steps) if world > 1 else None
         if not torch.isfinite(loss).item():
             raise SystemExit("bench.py: loss is not finite")
         ms, fl = C.c_double(0), C.c_double(0)
@@ -285,10 +440,11 @@ class Uncached:
             "config": {"workload": "Code_Uncached IISAN ViT-base+BERT-base, Amazon-Scientific-shaped synthetic batch, "
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
+                       **({"distributed": dinfo} if dinfo else {}),
                        **({"towers": "BERT on a second HIP stream beside ViT (opt-in; per-launch GEMM durations overlap other kernels)"}
                           if (a.overlap_towers if overlap is None else overlap) else {}),
-                       "encoder_blocks": "all tokens in every block (as HF)" if full_blocks else
-                                         "last block: K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
+                       "encoder_blocks": "all tokens in every block" if full_blocks else
+                                         "WORK PRUNING: last block computes K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_tflops / (MFMA_PEAK / 1e12),
                          # bytes per launch at the L2's memory side (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes of
@@ -404,11 +560,12 @@ def secondary_lines(a, unc, lib, dev, rank, world):
         except Exception as e:       # a secondary figure must never take the headline down with it
             out.append({"name": name, "error": f"{type(e).__name__}: {e}"})
 
-    add("uncached, every block on every token (as HF; SURVEY 8d-clean)", lambda: unc.line(k, w, "fp16", True, headline=False))
-    add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", False, headline=False))
+    add("uncached with WORK PRUNING (SURVEY 8d: reported separately, never the headline): the last encoder block runs attention/O/MLP "
+        "on the CLS rows only (taps identical)", lambda: unc.line(k, w, "fp16", False, headline=False))
+    add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", True, headline=False))
     unc.set_dtype(a.dtype)
     add("uncached, text tower on a second HIP stream beside the image tower (same results; its per-launch GEMM durations overlap "
-        "other kernels, so `roofline` is not a kernel measure here)", lambda: unc.line(k, w, a.dtype, False, headline=False, overlap=True))
+        "other kernels, so `roofline` is not a kernel measure here)", lambda: unc.line(k, w, a.dtype, True, headline=False, overlap=True))
     unc.set_dtype(a.dtype)
     c3 = argparse.Namespace(**{**vars(a), "cached": "fp32", "versa": False, "bs": 1024})
     add("BASELINE config 3: Code_Cached IISAN bs=1024, fp32 tap store", lambda: cached_line(c3, lib, dev, rank, world, 10, 3))
@@ -421,6 +578,9 @@ def secondary_lines(a, unc, lib, dev, rank, world):
     c5d = argparse.Namespace(**{**vars(c5), "dedup": True})
     add("IISAN-Versa bs=128 with the side network on DISTINCT item ids only (opt-in, loss bit-identical; reported separately)",
         lambda: cached_line(c5d, lib, dev, rank, world, 10, 3))
+    torch.cuda.empty_cache()
+    add("eval path at Scientific size (SURVEY 8f-2): evaluate_ranks / iisan_score_rank users/s, item_table items/s",
+        lambda: eval_line(a, lib, dev, rank, world))
     return out
 
 
@@ -450,8 +610,11 @@ def main():
 
     from iisan_amd import _lib
     lib = _lib.load()
-    lib.iisan_set_x3(a.x3)
-    if a.cached:
+    if a.x3 != 1:                       # 1 = the library's own default: leave the knob untouched
+        lib.iisan_set_x3(a.x3)
+    if a.eval:
+        out = eval_line(a, lib, dev, rank, world)
+    elif a.cached:
         out = cached_line(a, lib, dev, rank, world, a.steps, a.warmup)
     else:
         unc = Uncached(a, lib, dev, rank, world)
@@ -459,12 +622,14 @@ def main():
         out = unc.line(a.steps, a.warmup, a.dtype, a.full_blocks)
         if check:
             out["config"]["kernel_family_check"] = check
-        default = (world == 1 and a.bs == 128 and a.dtype == "fp16" and not a.full_blocks and not a.dedup
+        default = (world == 1 and a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup
                    and not a.overlap_towers and a.chunk == 0)
         if default and not a.no_secondary:
             out["secondary"] = secondary_lines(a, unc, lib, dev, rank, world)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    if _lib.dev_knobs():                 # a run with re-routed kernels must say so in its own line
+        out.setdefault("config", {})["dev_knobs"] = _lib.dev_knobs()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -132,12 +132,22 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # development aid (profiling a non-default route under rocprofv3): IISAN_DEV_KNOBS="sanb_fused=0,gemm32_k64=1" calls the
-    # one-argument iisan_set_<name>(int) knobs once at load time.  Unset in every product, test and bench run.
+    # one-argument iisan_set_<name>(int) knobs once at load time.  Unset in every product, test and bench run — and never
+    # silent: one stderr line says which kernels were re-routed, and bench.py copies `dev_knobs()` into its `config`.
     for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")):
         name, val = kv.split("=")
         getattr(lib, "iisan_set_" + name.strip())(int(val))
+    if dev_knobs():
+        import sys
+        print(f"iisan_amd: IISAN_DEV_KNOBS={dev_knobs()!r} is set: product kernel routes are overridden for this process",
+              file=sys.stderr, flush=True)
     _lib = lib
     return lib
+
+
+def dev_knobs() -> str:
+    """The IISAN_DEV_KNOBS override string of this process ('' = none: the product routes)."""
+    return ",".join(kv.strip() for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")))
 
 
 def check(rc: int, what: str):

@@ -855,7 +855,9 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();
-    // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it
+    // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it — the
+    // route is noted under the workspace so that the backward call follows what THIS call did, not the knob's later value
+    iisan_route_note(ws, ROUTE_CE, (rowpass_ok(bs, S) && g_ce_fast == 1) ? 1 : 0);
     if (rowpass_ok(bs, S) && g_ce_fast == 1 && S + 1 <= 11)
         hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr, g_ce_dbg);
     else if (rowpass_ok(bs, S) && g_ce_fast == 1)
@@ -887,7 +889,12 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    if (rowpass_ok(bs, S) && g_ce_fast == 1)
+    uint64_t fused = 0;
+    if (!iisan_route_find(ws, ROUTE_CE, &fused)) {
+        iisan_set_error("inbatch_ce_bwd: no inbatch_ce_fwd call has filled this workspace");
+        return IISAN_EBADSHAPE;
+    }
+    if (fused)        // d_prec for d_loss = 1 is in the workspace (whatever iisan_set_ce_fast says by now)
         hipLaunchKernelGGL(ce_scale_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(T * E / 4, 256), 1024)), dim3(256), 0, s, b.dprec, d_loss, d_prec, T * E / 4);
     else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_DPREC, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, d_loss, d_prec);

@@ -47,6 +47,27 @@ void iisan_set_error(const char* fmt, ...);
         if (_r != IISAN_OK) return _r;                                                                           \
     } while (0)
 
+// host-side note of the kernel route a forward call took on a workspace, read by its backward call (api.cpp)
+enum { ROUTE_CE = 1, ROUTE_SIDE_X3 = 2 };
+void iisan_route_note(const void* ws, uint32_t kind, uint64_t value);
+bool iisan_route_find(const void* ws, uint32_t kind, uint64_t* value);
+
+// per-device host caches (api.cpp).  iisan_cu_count(): compute units of the CURRENT device, asked of the runtime once per
+// device.  OncePerDevice: "this kernel's dynamic-LDS limit has been raised" is a fact about one device — a process that drives
+// a second device must raise it there too (a process-wide `static bool` made the second device's launches fail).
+constexpr int IISAN_MAX_DEVICES = 64;
+int iisan_cu_count();
+struct OncePerDevice {
+    bool done[IISAN_MAX_DEVICES] = {};
+    bool first() {                                       // true exactly once per device (single issuing thread per process)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IISAN_MAX_DEVICES) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -207,7 +228,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // per-launch HIP-event timing of the dominant kernel (timing.cpp); used by bench.py only
-bool iisan_timing_on();
+bool iisan_timing_on();          // class 1 (gemm16) enabled
+int iisan_timing_class();       // 0 = off, 1 = gemm16, 2 = the gemm32.hip family
 void iisan_timing_pre(hipStream_t s, double flops, double bytes);
 void iisan_timing_post(hipStream_t s);
 

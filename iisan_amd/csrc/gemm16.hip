@@ -245,12 +245,9 @@ bool gemm16_p256_applicable(const Gemm16Args& a);
 int launch_gemm16_p256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 bool gemm16_s256_applicable(int mode, const Gemm16Args& a);
 int launch_gemm16_s256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
-bool gemm16_w4_applicable(int mode, const Gemm16Args& a);
-int launch_gemm16_w4(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 
 // 0 = auto (persistent 256x256 kernels when the shape allows and there is at least half a tile per CU), 1 = force the
-// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel, 4 = the
-// one-wave-per-SIMD 256x256 kernel (gemm16_w4.hip).
+// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel.
 // Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
 static int g_auto_staggered = 1;
@@ -272,15 +269,8 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const bool timed = iisan_timing_on();
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N));
     const int var = g_variant & 0xff;
-    const bool big = var == 2 || var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    const bool big = var == 2 || var == 3 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
-    if (var == 4 && gemm16_w4_applicable(mode, a)) {         // experimental one-wave-per-SIMD kernel (gemm16_w4.hip)
-        Gemm16Args b = a;
-        b.debug = g_variant >> 8;
-        rc = launch_gemm16_w4(dtype16, mode, b, s);
-        if (timed) iisan_timing_post(s);
-        return rc;
-    }
     // auto policy (micro-benchmarks, tools/gemm_time.py): the staggered kernel wins on all four encoder GEMM shapes;
     // the lock-step one takes what the staggered one does not cover (fp32 / residual epilogues)
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {

@@ -244,17 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args p, int t
 
 template <typename T, int EPI>
 int launch_epi(const Gemm16Args& a, hipStream_t s) {
-    static bool attr_set = false;
+    static OncePerDevice attr;
     auto kern = gemm16_p256_kernel<T, EPI>;
-    if (!attr_set) {
+    if (attr.first())
         IISAN_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE_BYTES + 8192 * 4));
-        attr_set = true;
-    }
     const int tiles_m = (int)ceil_div(a.M, PBM), tiles_n = a.N / PBN;
     const int64_t ntiles = (int64_t)tiles_m * tiles_n;
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = iisan_cu_count();
     int grid = (int)(ntiles < cus ? ntiles : cus);
     grid = (grid + 7) / 8 * 8;          // the XCD walk needs a multiple of 8; surplus workgroups exit immediately
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * P_STAGE_BYTES + (size_t)a.N * 4, s, a, tiles_m, tiles_n);

@@ -418,9 +418,7 @@ static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, 
         IISAN_CHECK_SHAPE(towers[i].D == D && sanb_fused_ok(D, RD), "sanb: towers of one launch must share a supported width");
         fill(a.t[i], towers[i]);
     }
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = iisan_cu_count();
     const int64_t ntile = ceil_div(M, R);
     // persistent: one workgroup per CU and tower (three co-resident per CU), each walking tiles x, x + grid.x, ...
     const unsigned gx = (unsigned)((g_sanb_persist && ntile > cus) ? cus : ntile);
@@ -429,11 +427,9 @@ static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, 
 #define SANB_LAUNCH(DD)                                                                                                \
     do {                                                                                                               \
         auto k = BWD ? sanb_bwd_kernel<DD> : sanb_fwd_kernel<DD>;                                                      \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
+        static OncePerDevice attr;                                                                                     \
+        if (attr.first())                                                                                              \
             IISAN_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(DD))); \
-            attr_set = true;                                                                                           \
-        }                                                                                                              \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                                 \
     } while (0)
     switch (D) {

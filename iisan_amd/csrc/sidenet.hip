@@ -225,6 +225,15 @@ int g_use_x3 = 1;
 constexpr int64_t SANB_FUSED_MAX_ROWS = 4096;
 int g_use_sanb = 1;
 
+double gemm_x3_get_min_flops();
+// what decides which products take the split-operand route: the on/off knob and the FLOP threshold, as one comparable word
+uint64_t x3_route_word() {
+    const float f = (float)gemm_x3_get_min_flops();
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    return ((uint64_t)(g_use_x3 ? 1 : 0) << 32) | bits;
+}
+
 size_t x3_need(const Plan& p, int64_t M) {
     if (!g_use_x3) return 0;
     size_t need = 0;
@@ -404,12 +413,13 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 
 extern "C" void iisan_set_sanb_fused(int32_t on) { g_use_sanb = on; }
 
-void gemm_x3_set_min_flops(double f);
-// 0 = off, 1 = default (products of at least 8 GFLOP), 2 = every product whose shape allows it (tests: the small golden
-// fixtures then run through the split-operand path too)
+double gemm_x3_get_min_flops();
+void gemm_x3_set_min_flops(double f);     // negative = the library default (split.hip: X3_DEFAULT_MIN_FLOPS, 4 GFLOP)
+// 0 = off, 1 = library default (the state of a process that never calls this knob), 2 = every product whose shape allows
+// it (tests: the small golden fixtures then run through the split-operand path too)
 extern "C" void iisan_set_x3(int32_t mode) {
     g_use_x3 = mode != 0;
-    gemm_x3_set_min_flops(mode == 2 ? 0.0 : 8e9);
+    gemm_x3_set_min_flops(mode == 2 ? 0.0 : -1.0);
 }
 
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {
@@ -437,6 +447,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     ScratchGuard guard(b.skws, b.skws_floats);
     const int act_flag = cfg->gelu ? G32_GELU : G32_RELU;
     const int nsteps = p.diff_cv + p.diff_t + p.n[2];
+    iisan_route_note(ws, ROUTE_SIDE_X3, x3_route_word());     // the backward call must see the same split-operand routing
     IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE + X3Z_WORDS * X3Z_SLOTS_F) * sizeof(uint32_t), s));
     b.x3z_next = b.x3z_f; b.x3z_left = X3Z_SLOTS_F;
     // taps known to be exact in fp16 (cfg->taps_exact16): their amax slots are PRESET to 8192.0f, which the split kernels turn into
@@ -527,6 +538,17 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
     hipStream_t s = (hipStream_t)stream;
     Ctx c;
     IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_bwd"));
+    {   // the amax slots this call marks "ready" were filled by the forward call only on the routes IT took
+        uint64_t fwd_route = 0;
+        if (!iisan_route_find(ws, ROUTE_SIDE_X3, &fwd_route)) {
+            iisan_set_error("side_net_bwd: no side_net_fwd call has filled this workspace");
+            return IISAN_EBADSHAPE;
+        }
+        if (fwd_route != x3_route_word()) {
+            iisan_set_error("side_net_bwd: the split-operand routing (iisan_set_x3) changed since side_net_fwd filled this workspace");
+            return IISAN_EBADSHAPE;
+        }
+    }
     const Plan& p = c.p;
     SideBufs& b = c.b;
     ScratchGuard guard(b.skws, b.skws_floats);

@@ -238,8 +238,12 @@ static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
 //   172 vs 265 (1.5x) and its dW 133 vs 241 (1.8x); [4373,768]x[768,768] (the distinct ids of a bs = 1024 batch) 61 vs 86
 //   (1.4x), its dW 74 vs 75; [2816,768]x[768,768] 54 vs 50-55 (even); [1408,768]x[768,768] 45 vs 30 us (0.7x: stays on
 //   the f32 cores).
-static double g_x3_min_flops = 4e9;
-void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f; }
+// ONE default for the product, the tests and the bench (iisan_set_x3(1) restores exactly this value): products of at least
+// 4 GFLOP take the split-operand route ([4373, 768]x[768, 768] 61 vs 86 us; [2816, 768]x[768, 768] even)
+constexpr double X3_DEFAULT_MIN_FLOPS = 4e9;
+static double g_x3_min_flops = X3_DEFAULT_MIN_FLOPS;
+void gemm_x3_set_min_flops(double f) { g_x3_min_flops = f < 0 ? X3_DEFAULT_MIN_FLOPS : f; }
+double gemm_x3_get_min_flops() { return g_x3_min_flops; }
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags) {
     return x3_shape_ok(p, flags) && 2.0 * (double)p.M * (double)p.N * (double)p.K >= g_x3_min_flops;
 }

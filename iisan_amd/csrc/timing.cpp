@@ -1,6 +1,8 @@
-// Optional per-launch timing of the dominant kernel (gemm16) with HIP events recorded on the launching stream.
-// bench.py enables it around its timed region to report the roofline fraction of that kernel; disabled it costs
-// one branch per launch.  Not part of the product ABI (declared in common.h only; exported for bench.py).
+// Optional per-launch timing of the dominant kernel family with HIP events recorded on the launching stream: class 1 = the
+// 16-bit encoder GEMM (gemm16*, the Uncached headline), class 2 = the f32-matrix-core GEMM family of the trainable side
+// (gemm32.hip: tiled / K = 64 / N = 64 + fusion / weight-gradient kernels — the dominant family of the Cached and Versa steps).
+// bench.py enables ONE class around its timed region to report that family's roofline fraction; disabled it costs one branch
+// per launch.  Not part of the product ABI (declared in common.h only; exported for bench.py).
 #include <vector>
 
 #include "common.h"
@@ -8,7 +10,7 @@
 namespace {
 struct Rec { hipEvent_t a, b; double flops, bytes; };
 double g_last_bytes = 0;
-bool g_on = false;
+int g_on = 0;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t take() {
@@ -19,7 +21,8 @@ hipEvent_t take() {
 }
 }  // namespace
 
-bool iisan_timing_on() { return g_on; }
+bool iisan_timing_on() { return g_on == 1; }
+int iisan_timing_class() { return g_on; }
 void iisan_timing_pre(hipStream_t s, double flops, double bytes) {
     Rec r{take(), take(), flops, bytes};
     hipEventRecord(r.a, s);
@@ -27,7 +30,7 @@ void iisan_timing_pre(hipStream_t s, double flops, double bytes) {
 }
 void iisan_timing_post(hipStream_t s) { hipEventRecord(g_recs.back().b, s); }
 
-extern "C" void iisan_timing_enable(int on) { g_on = on != 0; }
+extern "C" void iisan_timing_enable(int cls) { g_on = cls; }
 // Synchronises on the recorded events; returns the number of launches and fills total milliseconds / total FLOPs.
 extern "C" int64_t iisan_timing_collect(double* total_ms, double* total_flops) {
     double ms = 0, fl = 0, by = 0;

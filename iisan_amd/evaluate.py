@@ -93,14 +93,21 @@ def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[i
         out.append(ops.score_rank(prec, item_emb, hist[i:i + batch].to(dev), tgt[i:i + batch].to(dev)))
     model.train(was_training)
     ranks = torch.cat(out)
-    return dp.gather_concat(ranks, U) if world > 1 else ranks
+    ranks = dp.gather_concat(ranks, U) if world > 1 else ranks
+    # `iisan_score_rank` reports -1 for a target outside 1..item_num; the reference indexes the score row with it and raises
+    # IndexError (metrics.py:206) — so does this, after the gather, on every rank alike
+    if bool((ranks < 1).any()):
+        bad = torch.nonzero(ranks < 1).flatten()[:8].tolist()
+        raise IndexError(f"evaluate_ranks: target item id outside 1..{item_emb.shape[0] - 1} for users {bad}")
+    return ranks
 
 
 def hit_ndcg(ranks: torch.Tensor, topk: int = 10) -> Tuple[float, float]:
     """Hit@k and nDCG@k as `metrics_topK` + `eval_concat` report them (metrics.py:50-67)."""
     r = ranks.to(torch.float64)
-    hit = (r <= topk).to(torch.float64)
-    ndcg = torch.where(r <= topk, 1.0 / torch.log2(r + 1.0), torch.zeros_like(r))
+    ok = (r >= 1) & (r <= topk)              # a rank < 1 is the kernel's "invalid target" signal, never a hit
+    hit = ok.to(torch.float64)
+    ndcg = torch.where(ok, 1.0 / torch.log2(r.clamp(min=1.0) + 1.0), torch.zeros_like(r))
     return float(hit.mean()), float(ndcg.mean())
 
 

@@ -119,6 +119,9 @@ class FlatTrainer:
         self.seg_end.append(total)
         self.seg_lr.append(lrs[cur])
         self.step_no = 0
+        # optional: HIP events around the one data-path collective (bench.py: all-reduce time per step, read after a sync)
+        self.time_allreduce = False
+        self._ar_events = []
 
     def broadcast_params(self):
         if self.world > 1:
@@ -136,11 +139,29 @@ class FlatTrainer:
         finally:
             ops.DIRECT_PARAM_GRADS = prev
         if self.world > 1:
-            dp.allreduce_sum_(self.grad)                        # the ONE data-path collective (DDP grad average)
+            if self.time_allreduce:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dp.allreduce_sum_(self.grad)
+                e1.record()
+                self._ar_events.append((e0, e1))
+            else:
+                dp.allreduce_sum_(self.grad)                    # the ONE data-path collective (DDP grad average)
         self.step_no += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.seg_end, self.seg_lr, self.step_no,
                       grad_scale=1.0 / self.world)              # run.py:413
         return loss
+
+
+    def allreduce_ms(self, reset: bool = True):
+        """(number of timed all-reduces, their total device time in ms) since the last reset; call after a device sync.
+        The events sit on the stream the collective is enqueued on (torch's current stream: RCCL orders its own stream
+        against it on both sides), so the span covers the wait for RCCL's stream as well as the transfer."""
+        n = len(self._ar_events)
+        ms = sum(a.elapsed_time(b) for a, b in self._ar_events)
+        if reset:
+            self._ar_events = []
+        return n, ms
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -35,19 +35,29 @@ def _run_ranks(world, backend):
     out = tempfile.mkdtemp(prefix="iisan_dp_")
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                DP_BACKEND=backend, DP_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # every rank writes to its own FILE: with pipes drained one after the other, a rank that fills its pipe buffer (RCCL / gloo
+    # warnings, a traceback) blocks, its peer waits for it in a collective, and the test hangs to the timeout instead of
+    # showing the error
+    logs = [open(os.path.join(out, f"rank{r}.log"), "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_gpu_worker.py")], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(o)
+                              stdout=logs[r], stderr=subprocess.STDOUT, text=True) for r in range(world)]
+
+    def tail(r):
+        logs[r].flush()
+        logs[r].seek(0)
+        return logs[r].read()[-4000:]
+
+    try:
+        for p in procs:
+            p.wait(timeout=600)
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise AssertionError("ranks timed out:\n" + "\n".join(f"--- rank {r} ---\n{tail(r)}" for r in range(world)))
     for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-4000:]}"
+        assert p.returncode == 0, "rank %d failed:\n" % r + "\n".join(f"--- rank {q} ---\n{tail(q)}" for q in range(world))
+    for f in logs:
+        f.close()
     return [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=False) for r in range(world)]
 
 

@@ -255,3 +255,12 @@ def test_bench_starts_its_own_ranks_and_describes_the_host():
     assert bench.parse([]).bs == 128 and bench.parse(["--cached", "fp32"]).bs == 1024 and bench.parse(["--cached", "fp16", "--versa"]).bs == 128
     cores, model = bench.host_cpu()
     assert 1 <= cores <= (os.cpu_count() or 1) and isinstance(model, str) and model
+
+
+def test_hit_ndcg_never_counts_the_invalid_target_signal_as_a_hit():
+    """`iisan_score_rank` answers -1 for a target outside 1..item_num (the reference raises IndexError, metrics.py:206);
+    `hit_ndcg` must not read that as rank <= 10."""
+    from iisan_amd import evaluate
+    hit, ndcg = evaluate.hit_ndcg(torch.tensor([1, 3, 11, -1]))
+    assert abs(hit - 2 / 4) < 1e-12
+    assert abs(ndcg - (1.0 + 0.5) / 4) < 1e-12
