@@ -34,6 +34,8 @@ int launch_sanb_fwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hip
 int launch_sanb_bwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s);
 int launch_sanb_transpose(const float* const* in, float* const* out, const int32_t* rows, const int32_t* cols, int n, hipStream_t s);
 
+double gemm_x3_get_min_flops();     // split.hip
+
 namespace {
 
 // one tower of one fusion step.  type 0: F = g·a + (1-g)·prev ; type 1: F = prev + g·a + (1-g)·b  (not gated: plain sums)
@@ -225,7 +227,6 @@ int g_use_x3 = 1;
 constexpr int64_t SANB_FUSED_MAX_ROWS = 4096;
 int g_use_sanb = 1;
 
-double gemm_x3_get_min_flops();
 // what decides which products take the split-operand route: the on/off knob and the FLOP threshold, as one comparable word
 uint64_t x3_route_word() {
     const float f = (float)gemm_x3_get_min_flops();
@@ -413,7 +414,6 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 
 extern "C" void iisan_set_sanb_fused(int32_t on) { g_use_sanb = on; }
 
-double gemm_x3_get_min_flops();
 void gemm_x3_set_min_flops(double f);     // negative = the library default (split.hip: X3_DEFAULT_MIN_FLOPS, 4 GFLOP)
 // 0 = off, 1 = library default (the state of a process that never calls this knob), 2 = every product whose shape allows
 // it (tests: the small golden fixtures then run through the split-operand path too)
