@@ -245,12 +245,19 @@ bool gemm16_p256_applicable(const Gemm16Args& a);
 int launch_gemm16_p256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 bool gemm16_s256_applicable(int mode, const Gemm16Args& a);
 int launch_gemm16_s256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+bool gemm16_h256_applicable(int mode, const Gemm16Args& a);
+int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 
 // 0 = auto (persistent 256x256 kernels when the shape allows and there is at least half a tile per CU), 1 = force the
-// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel.
+// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel (gemm16_s256.hip), 4 = force
+// the staggered kernel with the half-slot tile boundary (gemm16_h256.hip).
 // Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
 static int g_auto_staggered = 1;
+// auto policy: which staggered kernel takes the production shapes — 1 = gemm16_h256.hip (epilogue hidden in half-slots),
+// 0 = gemm16_s256.hip.  Knob for the same-box A/B (tools/gemm_ab.py).
+static int g_auto_h256 = 0;
+extern "C" void iisan_set_gemm16_h256(int32_t on) { g_auto_h256 = on; }
 // 1: the staggered kernel starts its workgroups up to ~one tile time apart on the short-K products with store-heavy
 // epilogues (QKV scatter, FC1 GELU), so the CUs' store bursts stop coinciding (tools/gemm_time.py: QKV 963 -> 988, FC1 900 ->
 // 913 TF; O -2 %, FC2 -7 %: not applied there).  Knob for the A/B (tools/desync_ab.py).
@@ -269,8 +276,15 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const bool timed = iisan_timing_on();
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N));
     const int var = g_variant & 0xff;
-    const bool big = var == 2 || var == 3 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    const bool big = var == 2 || var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
+    if (big && (var == 4 || (var == 0 && g_auto_staggered && g_auto_h256)) && gemm16_h256_applicable(mode, a)) {
+        Gemm16Args b = a;
+        b.debug = g_variant >> 8;
+        rc = launch_gemm16_h256(dtype16, mode, b, s);
+        if (timed) iisan_timing_post(s);
+        return rc;
+    }
     // auto policy (micro-benchmarks, tools/gemm_time.py): the staggered kernel wins on all four encoder GEMM shapes;
     // the lock-step one takes what the staggered one does not cover (fp32 / residual epilogues)
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {

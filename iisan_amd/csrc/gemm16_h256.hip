@@ -1,0 +1,556 @@
+// Fourth-generation 16-bit MFMA GEMM: the staggered 256x256x64 kernel (gemm16_s256.hip) with a HALF-SLOT TILE BOUNDARY.
+//
+// What s256 loses: with K = 768 a tile is only 12 K-steps long, and at every tile boundary the epilogue (bias,
+// GELU, 16-bit convert, 128 KiB of stores per tile) got slots of its own —
+//        A: M(L) | E1 | E2+R(0') | M(0')         one slot with NO MFMA at all per tile, two more stretched by the stores:
+//        B: R(L) | M(L) | E1     | E2+R(0')      QKV 986 / FC1 873-950 TFLOP/s against 1,260-1,280 without an epilogue.
+// An epilogue can only overlap the sibling group's MFMAs while its accumulators are not needed by the own group's next
+// MFMAs.  So the LAST K-step L of a tile and the FIRST K-step 0' of the next are each cut into two half-steps by output
+// rows: "lo" = the group's rows 0..63 (acc[0..1][*]), "hi" = rows 64..127 (acc[2..3][*]):
+//
+//        A:  Rlo(L) Mlo(L) [Rhi(L)+Elo] Mhi(L) | Rlo(0') Mlo(0') [Rhi(0')+Ehi] Mhi(0') | R(1') M(1') ...
+//        B:  one slot behind, same program
+//
+// The lo accumulators are final after Mlo(L): their epilogue Elo runs in the NEXT read slot, beside the sibling's MFMAs, and
+// must be done before Mlo(0') overwrites them; the hi accumulators are final after Mhi(L) and are flushed in the read slot
+// between Mlo(0') and Mhi(0').  Every slot of the boundary carries MFMAs (16 instead of 32), no slot is epilogue-only, and no
+// extra register is needed (a half-step holds 64 fragment registers instead of 96).  Cost: three more barriers per tile.
+//
+// LDS-DMA schedule (ring, pieces and their owners as in s256; plan(s) = 8 pieces: 0..3 / 4..7):
+//        group A plan(s): 0..3 = B's A-operand half of step s+1, 4..7 = A's own half of step s+2
+//        group B plan(s): 0..3 = W rows 0..127 of step s+2,      4..7 = W rows 128..255 of step s+2
+//   middle step  M(s)   : all 8 pieces of plan(s), one after every 4 MFMAs (as s256)
+//   last step    Mlo(L) : pieces 0..3 of plan(L);            Mhi(L)  : none
+//   first step   Mlo(0'): pieces 4..7 of plan(L) + 0..3 of plan(0') (one after every 2 MFMAs);  Mhi(0'): 4..7 of plan(0')
+// Nothing is issued in Mhi(L): a load issued there would be YOUNGER than Elo's stores, and `vmcnt` retires in order on gfx9
+// — the wait for it at the end of Rlo(0') would wait for the stores as well.  As scheduled, every wait at the end of an
+// [R+E] slot is `vmcnt(8)` (the 8 stores of that half-epilogue stay in flight), Rlo(0') needs no wait at all, and only the
+// wait at the end of R(1') covers stores — Ehi's, two slots old.  Buffer safety (slot numbers: A's Rlo(L) = 1):
+//   A Mlo(L)  [2]: B's half of 0'  -> read by B in [6],[8]; buffer last read by B in [0];      waited by A at the end of [3]
+//   A Mlo(0') [6]: own half of 1'  -> read by A in [9];     buffer last read by A in [1],[3];  waited at the end of [7]
+//                  B's half of 1'  -> read by B in [10];    buffer last read by B in [2],[4]
+//   A Mhi(0') [8]: own half of 2'  -> read by A in [11];    buffer last read by A in [5],[7];  waited at the end of [9]
+//   B Mlo(L)  [3]: W 0..127 of 1'  -> read in [9],[10];     W buffer last read in [1],[2];     waited by B at the end of [4]
+//   B Mlo(0') [7]: W 128..255 of 1'-> read in [9],[10];     ditto;                             waited at the end of [8]
+//                  W 0..127 of 2'  -> read in [11],[12];    W buffer last read in [5],[6]
+//   B Mhi(0') [9]: W 128..255 of 2'-> read in [11],[12];                                       waited at the end of [10]
+// (the whole W fragment set of a step is read in Rlo, the A-operand rows 0..63 in Rlo and 64..127 in Rhi).
+// Tile walk, LDS swizzle, operand swap / W-row permutation, fences and the 16-bit epilogues are those of gemm16_s256.hip.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int SBM = 256, SBN = 256, SBK = 64;
+constexpr int S_OP_BYTES = SBM * SBK * 2;        // 32 KiB per operand tile
+constexpr int S_STAGE_BYTES = 2 * S_OP_BYTES;    // 64 KiB per K-step
+
+template <typename T> struct Mfma32s;
+template <> struct Mfma32s<F16> {
+    static __device__ __forceinline__ f16v run(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma32s<BF16> {
+    static __device__ __forceinline__ f16v run(b8 a, b8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 2) & 1) + 4 * ((q & 31) >> 3) + (q & 3); }
+
+#define S256_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define S256_BARRIER()                                   \
+    do {                                                 \
+        S256_FENCE();                                    \
+        asm volatile("s_barrier" ::: "memory");          \
+        S256_FENCE();                                    \
+    } while (0)
+#define S256_VMCNT(n)                                        \
+    do {                                                     \
+        S256_FENCE();                                        \
+        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
+        S256_FENCE();                                        \
+    } while (0)
+#define S256_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n) {
+    typedef typename T::v8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + N floats of bias
+    float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 0 = A (tile rows 0..127), 1 = B (rows 128..255).  The YOUNGER half of the workgroup (waves 4..7) is group A: on every
+    // SIMD the younger wave loses arbitration to its older sibling, so its MFMA slot runs longer (slot timelines: 1,640 vs
+    // 1,252 cycles with the older waves as A; 1,400 vs 1,276 this way round) — it gets the lighter DMA duty (A-operand
+    // halves; group B streams the W tile that every CU hammers) and the leading position.
+    const int grp = 1 - (wave >> 2);
+    const int wq = wave & 3;              // wave within the group = its 64-column slice of the tile
+
+    const int G = gridDim.x;
+    const int pid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int ntiles = tiles_m * tiles_n;
+    const int my_tiles = pid < ntiles ? (ntiles - pid + G - 1) / G : 0;
+    const int nk = p.K / SBK;
+    const int nsteps = my_tiles * nk;
+    if (nsteps == 0) return;
+
+    // staging offsets, kept to 5 VGPRs: lane -> row-in-chunk r8 = lane>>3, physical slot lane&7; the logical slot is
+    // physical ^ ((row>>1)&7) = s0 ^ 4*(j&1) for chunk j of a 32-row-aligned run, s0 = (lane&7) ^ (lane>>4).
+    const int r8 = lane >> 3;
+    const int s0 = (lane & 7) ^ (lane >> 4);
+    const int slotx0 = s0 * 16, slotx1 = (s0 ^ 4) * 16;
+    const int rowA = r8 * p.lda * 2;                                             // A-operand: LDS row == global row
+    const int rowW = (16 * ((r8 >> 2) & 1) + (r8 & 3)) * p.ldw * 2;              // W: permuted rows (nperm32s)
+    const char* Abase = (const char*)p.A;
+    const char* Wbase = (const char*)p.W;
+
+    // One 1-KiB piece (8 LDS rows) of the A-operand half `h` / the W half `h` of flat step s; wave wq owns rows
+    // h*128 + wq*32 .. +31 of a half, piece j = rows +8j.
+    auto piece_A = [&](int s, int h, int j) {
+        const int ti = s / nk, kt = s - ti * nk;
+        const int tau = pid + ti * G;
+        const int tm = tau / tiles_n;
+        const int q0 = h * 128 + wq * 32;
+        const char* Ag = Abase + (((int64_t)tm * SBM + q0 + 8 * j) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
+        glds16(Ag + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + (q0 + 8 * j) * 128);
+    };
+    auto piece_W = [&](int s, int h, int j) {   // LDS rows q0+8j.. hold W rows q0 + 4j + {0,16} + {0..3} (nperm32s)
+        const int ti = s / nk, kt = s - ti * nk;
+        const int tau = pid + ti * G;
+        const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+        const int q0 = h * 128 + wq * 32;
+        const char* Wg = Wbase + (((int64_t)tn * SBN + q0 + 4 * j) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
+        glds16(Wg + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (q0 + 8 * j) * 128);
+    };
+
+    f16v acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    int xoff[4], woff2[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) xoff[mi] = (grp * 128 + mi * 32 + frow) * 128;   // group g reads only its A-half
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) woff2[ni] = (wq * 64 + ni * 32 + frow) * 128;
+
+    V8 wf[2][4], xf[4][4];
+    auto read_step = [&](int s) {
+        const char* sA = smem + (s & 1) * S_STAGE_BYTES;
+        const char* sW = sA + S_OP_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ((2 * ks + fh) ^ fsw) << 4;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) wf[ni][ks] = *(const V8*)(sW + woff2[ni] + slot);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) xf[mi][ks] = *(const V8*)(sA + xoff[mi] + slot);
+        }
+    };
+    // half-steps of a tile's last / first K-step: Rlo = every W fragment of the step + the A-operand rows 0..63 of the
+    // group's half (16 reads), Rhi = rows 64..127 (8 reads)
+    auto read_lo = [&](int s) {
+        const char* sA = smem + (s & 1) * S_STAGE_BYTES;
+        const char* sW = sA + S_OP_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ((2 * ks + fh) ^ fsw) << 4;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) wf[ni][ks] = *(const V8*)(sW + woff2[ni] + slot);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) xf[mi][ks] = *(const V8*)(sA + xoff[mi] + slot);
+        }
+    };
+    auto read_hi = [&](int s) {
+        const char* sA = smem + (s & 1) * S_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ((2 * ks + fh) ^ fsw) << 4;
+#pragma unroll
+            for (int mi = 2; mi < 4; ++mi) xf[mi][ks] = *(const V8*)(sA + xoff[mi] + slot);
+        }
+    };
+    // ---- DMA plan of one MFMA slot: 8 wave-uniform (global address, LDS offset) pairs, computed in the preceding READ
+    // slot (which idles ~1000 cycles at its barrier).  Nothing but the MFMAs, one 64-bit add, `s_mov m0` and the
+    // `global_load_lds` itself may sit in the MFMA slot: slot timelines showed every scalar instruction or branch between
+    // MFMAs to cost matrix-pipe time (an MFMA slot took 1440 cycles with 8 skipped `if`s, 1540 with 32, 1046 bare).
+    // The plan is therefore unconditional: past the end of the workgroup's steps it re-loads the last step into
+    // buffers that nobody reads any more.
+    struct Plan {
+        uint32_t g1lo, g1hi, g2lo, g2hi;      // global byte address of pieces 0..3 / 4..7 (SGPRs)
+        uint32_t l1, l2;                      // LDS byte offset of piece 0 / piece 4
+    };
+    // per-lane source offset of piece j (j = pc & 3): row-in-chunk and swizzled 16-B slot, plus j chunks of 8 (A operand)
+    // or 4 (permuted W) rows
+    uint32_t vj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        vj[j] = (uint32_t)((grp == 0 ? rowA : rowW) + ((j & 1) ? slotx1 : slotx0)) + (uint32_t)j * (grp == 0 ? 8u * p.lda * 2u : 4u * p.ldw * 2u);
+    auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // Group A: pieces 0..3 = B's A-operand half of step s+1, 4..7 = A's own half of step s+2;
+    // group B: the W tile of step s+2 (pieces 0..3 rows 0..127, 4..7 rows 128..255).
+    auto make_plan = [&](int s) {
+        Plan q;
+        const int last = nsteps - 1;
+        uint64_t g1, g2;
+        if (grp == 0) {
+            const int s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last;
+            const int ti1 = s1 / nk, kt1 = s1 - ti1 * nk, tm1 = (pid + ti1 * G) / tiles_n;
+            const int ti2 = s2 / nk, kt2 = s2 - ti2 * nk, tm2 = (pid + ti2 * G) / tiles_n;
+            g1 = (uint64_t)Abase + (((int64_t)tm1 * SBM + 128 + wq * 32) * p.lda + (int64_t)kt1 * SBK) * 2;
+            g2 = (uint64_t)Abase + (((int64_t)tm2 * SBM + wq * 32) * p.lda + (int64_t)kt2 * SBK) * 2;
+            q.l1 = ((s + 1) & 1) * S_STAGE_BYTES + (128 + wq * 32) * 128;
+            q.l2 = (s & 1) * S_STAGE_BYTES + (wq * 32) * 128;
+        } else {
+            const int s2 = s + 2 < last ? s + 2 : last;
+            const int ti = s2 / nk, kt = s2 - ti * nk;
+            const int tau = pid + ti * G;
+            const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+            g1 = (uint64_t)Wbase + (((int64_t)tn * SBN + wq * 32) * p.ldw + (int64_t)kt * SBK) * 2;
+            g2 = g1 + (uint64_t)128 * p.ldw * 2;
+            q.l1 = (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (wq * 32) * 128;
+            q.l2 = q.l1 + 128 * 128;
+        }
+        q.g1lo = sgpr((uint32_t)g1); q.g1hi = sgpr((uint32_t)(g1 >> 32));
+        q.g2lo = sgpr((uint32_t)g2); q.g2hi = sgpr((uint32_t)(g2 >> 32));
+        q.l1 = sgpr(q.l1); q.l2 = sgpr(q.l2);
+        return q;
+    };
+    // 32 MFMAs with this wave's 8 DMA pieces interleaved: piece pc after MFMA 4*pc + 3.  Only the 8 MFMAs of K-slice 0
+    // exist in two versions (a tile's first K-step starts from C = 0, an inline-constant operand, instead of zeroing
+    // 128 VGPRs): with two full bodies the compiler hoisted the 8 piece addresses above the branch -> 16 VGPRs, spills,
+    // and a `s_waitcnt vmcnt(0)` for the reload at the top of every MFMA slot.
+    auto mfma_step = [&](const Plan& q, bool first) {
+        auto piece = [&](int pc) {
+            const int j = pc & 3;
+            const uint64_t gb = ((uint64_t)(pc < 4 ? q.g1hi : q.g2hi) << 32) | (pc < 4 ? q.g1lo : q.g2lo);
+            S256_FENCE();
+            // SGPR base + 32-bit lane offset, written as inline asm: the builtin is selected with a 64-bit VGPR address
+            // (a v_lshl_add_u64 per piece between the MFMAs and two address registers read per lane).  Same-box A/B
+            // over 6 rounds: QKV 915 -> 921, O 940 -> 942, FC1 921 -> 931, FC2 1146 -> 1162 TFLOP/s.  (M0 is only
+            // written here and, in the prologue, by the builtin right before its own use.)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(smem_lds + (pc < 4 ? q.l1 : q.l2) + j * 1024), "v"(vj[j]), "s"(gb) : "memory");
+            S256_FENCE();
+        };
+        auto slice = [&](auto FIRST, int ks) {
+            f16v zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = Mfma32s<T>::run(wf[ni][ks], xf[mi][ks], decltype(FIRST)::value ? zero : acc[mi][ni]);
+                    if (((mi * 2 + ni) & 3) == 3) piece(ks * 2 + (mi >> 1));
+                }
+        };
+        // The sibling wave of this SIMD is in its read slot (ds_reads, address VALU, plan SALU): with equal priority the
+        // arbiter prefers the OLDER wave, and the slot timeline showed group B's MFMA slots at 1,680 cycles against
+        // group A's 1,252.  Priority 1 for whoever is on the matrix pipe removes that.
+        __builtin_amdgcn_s_setprio(1);
+        if (first) slice(std::true_type{}, 0); else slice(std::false_type{}, 0);
+        S256_FENCE();
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) slice(std::false_type{}, ks);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // One half-step: the 16 MFMAs of output rows lo (HI = 0: acc[0..1]) or hi (HI = 1: acc[2..3]) of a K-step, with the DMA
+    // pieces the schedule in the file header assigns to it (MODE, compile time — nothing but MFMAs and pieces in the slot):
+    //   H_LAST_LO : pieces 0..3 of q (one after every 4 MFMAs)            H_LAST_HI : none
+    //   H_FIRST_LO: pieces 4..7 of qp (the previous tile's last plan) and 0..3 of q, one after every 2 MFMAs; C = 0 at ks 0
+    //   H_FIRST_HI: pieces 4..7 of q;                                                                      C = 0 at ks 0
+    enum { H_LAST_LO = 0, H_LAST_HI = 1, H_FIRST_LO = 2, H_FIRST_HI = 3 };
+    auto mfma_half = [&](auto MODE_T, const Plan& q, const Plan& qp) {
+        constexpr int MODE = decltype(MODE_T)::value;
+        constexpr int HI = MODE & 1;
+        constexpr bool FIRST = MODE >= 2;
+        auto piece = [&](uint32_t lo32, uint32_t hi32, uint32_t lds, int j) {
+            const uint64_t gb = ((uint64_t)hi32 << 32) | lo32;
+            S256_FENCE();
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(smem_lds + lds + j * 1024), "v"(vj[j]), "s"(gb) : "memory");
+            S256_FENCE();
+        };
+        f16v zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int mi = 2 * HI + m2;
+                    const int n = ks * 4 + m2 * 2 + ni;               // 0..15: index of this MFMA in the half-step
+                    acc[mi][ni] = Mfma32s<T>::run(wf[ni][ks], xf[mi][ks], (FIRST && ks == 0) ? zero : acc[mi][ni]);
+                    if constexpr (MODE == H_LAST_LO) {
+                        if ((n & 3) == 3) piece(q.g1lo, q.g1hi, q.l1, n >> 2);
+                    } else if constexpr (MODE == H_FIRST_HI) {
+                        if ((n & 3) == 3) piece(q.g2lo, q.g2hi, q.l2, n >> 2);
+                    } else if constexpr (MODE == H_FIRST_LO) {
+                        if ((n & 1) == 1) {
+                            const int pc = n >> 1;                    // 0..7: 0..3 = qp's pieces 4..7, 4..7 = q's pieces 0..3
+                            if (pc < 4) piece(qp.g2lo, qp.g2hi, qp.l2, pc); else piece(q.g1lo, q.g1hi, q.l1, pc - 4);
+                        }
+                    }
+                }
+            if (FIRST && ks == 0) S256_FENCE();
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    bool stores16 = false;     // the last epilogue issued exactly 16 store instructions per wave (full row tile, stores enabled)
+    auto epilogue = [&](int s, int half) {
+        const int ti = s / nk;
+        const int tau = pid + ti * G;
+        const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+        stores16 = ((int64_t)(tm + 1) * SBM <= p.M) && !(p.debug & 1);
+        // head-major QKV: this wave's 64 columns are one (q|k|v, head) pair -> wave-uniform; (item, token) of a row by
+        // ONE 32-bit division per tile, then advanced by 32 rows per block (a 64-bit division per block cost ~800
+        // VALU instructions per tile and wave)
+        unsigned qk_which = 0, qk_hd = 0, qk_item = 0, qk_tok = 0;
+        const unsigned qk_S = (unsigned)p.qkv_S;
+        if constexpr (EPI == EPI_QKVH16) {
+            const unsigned Dm = (unsigned)p.qkv_heads * 64u, n64 = (unsigned)(tn * SBN + wq * 64);
+            const unsigned wq_ = n64 / Dm;
+            qk_hd = (n64 - wq_ * Dm) >> 6;
+            qk_which = wq_ + (unsigned)p.qkv_which0;
+            const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + half * 64 + frow);
+            qk_item = m0 / qk_S;
+            qk_tok = m0 - qk_item * qk_S;
+        }
+        // the lane's 32 bias values (its columns are the same for every 32-row block) are read from LDS ONCE per epilogue
+        // half, up front — read inside the block loop, each block's four reads sat right before their adds behind an
+        // lgkmcnt(0) (ISA): eight exposed LDS round trips per epilogue half
+        f4 bbv[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                bbv[ni][q4] = p.bias ? *(const f4*)(sBias + tn * SBN + wq * 64 + ni * 32 + 16 * fh + 4 * q4) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if ((mi >> 1) != half) continue;
+            const int64_t m = (int64_t)tm * SBM + grp * 128 + mi * 32 + frow;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int n = tn * SBN + wq * 64 + ni * 32 + 16 * fh;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
+                if (m >= p.M || (p.debug & 1)) continue;
+
+                typename T::elem* op;
+                if constexpr (EPI == EPI_QKVH16) {
+                    op = (typename T::elem*)p.out + ((((int64_t)qk_item * p.qkv_heads + qk_hd) * 3 + qk_which) * qk_S + qk_tok) * 64 + (ni * 32 + 16 * fh);
+                } else {
+                    op = (typename T::elem*)p.out + m * p.ldo + n;
+                }
+                f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = (f2){v[2 * k], v[2 * k + 1]} + (f2){bbv[ni][k >> 1][2 * (k & 1)], bbv[ni][k >> 1][2 * (k & 1) + 1]};
+                if constexpr (EPI == EPI_GELU16) gelu_erf_fast2x8(g);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    V8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        o[e] = T::from_f32(g[4 * h2 + e / 2][0]);
+                        o[e + 1] = T::from_f32(g[4 * h2 + e / 2][1]);
+                    }
+                    *(V8*)(op + 8 * h2) = o;
+                }
+            }
+            if constexpr (EPI == EPI_QKVH16) {
+                qk_tok += 32;
+                while (qk_tok >= qk_S) { qk_tok -= qk_S; ++qk_item; }
+            }
+        }
+        // the accumulators are dead now (the next K-step is a tile's first and starts from C = 0); an empty asm that
+        // "defines" them tells the register allocator so — otherwise it copies all 128 of them before the bias add
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
+    };
+
+    const long long dbg_t0 = __builtin_readcyclecounter();
+    // development aid (build with -DS256_TIMELINE, run with debug bit 16): wave 0 of each group stamps the cycle counter
+    // at slot boundaries into LDS, dumped to out[] at the end; tools/gemm_slots.py prints the timeline.  Compiled out by
+    // default: even the disabled checks cost ~5 % (everything between MFMAs does).
+#ifdef S256_TIMELINE
+    unsigned* sStamp = (unsigned*)(smem + 2 * S_STAGE_BYTES + p.N * 4) + grp * 1024;
+    int dbg_n = 0;
+    const bool dbg_on = (p.debug & 16) && blockIdx.x == 0 && wq == 0;
+    auto stamp = [&]() {
+        if (dbg_on && dbg_n < 1024) {
+            if (lane == 0) sStamp[dbg_n] = (unsigned)(__builtin_readcyclecounter() - dbg_t0);
+            ++dbg_n;
+        }
+    };
+#else
+    auto stamp = [] {};
+#endif
+    if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
+        const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    if (p.debug & 8) {                         // experiment: one phase per XCD (L2 sharing inside an XCD is kept), spread over
+        const int units = (int)(blockIdx.x & 7) * nk * ((p.debug >> 8) & 15) / 12;     // (debug>>8)&15 kilo-cycles per XCD at K=768
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    if (p.bias)
+        for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias[i];
+    __syncthreads();
+
+    // ---- prologue: what the steady-state rules would have issued before slot 0 ----
+    if (grp == 0) {
+        for (int j = 0; j < 4; ++j) piece_W(0, 0, j);
+        for (int j = 0; j < 4; ++j) piece_A(0, 1, j);
+        S256_VMCNT(0);
+    } else {
+        for (int j = 0; j < 4; ++j) piece_A(0, 0, j);
+        for (int j = 0; j < 4; ++j) piece_W(0, 1, j);
+        if (nsteps > 1) {
+            for (int j = 0; j < 4; ++j) piece_A(1, 0, j);
+            for (int j = 0; j < 8; ++j) piece_W(1, j >> 2, j & 3);
+            S256_VMCNT(12);
+        } else {
+            S256_VMCNT(0);
+        }
+    }
+    S256_BARRIER();                                   // P: W(0) and both A-halves of step 0 are in LDS
+
+    // One group's program; B runs the same one slot behind (its extra barrier in front, A's at the end).  `stores8`: the
+    // half-epilogue of this slot issued exactly 8 store instructions (full row tile, stores enabled), all YOUNGER than the
+    // loads the wait is for: `vmcnt(8)` lets them fly on.
+    using std::integral_constant;
+    Plan qprev = make_plan(-1);        // pieces 4..7: what the prologue loaded for step 1 (re-issued identically at s = 0)
+    if (grp == 1) S256_BARRIER();      // B: slot 0 (A is in Rlo(0))
+    for (int s = 0; s < nsteps;) {
+        {
+            // ======== first K-step of a tile: Rlo | Mlo | Rhi + Ehi(previous tile) | Mhi ========
+            read_lo(s);
+            const Plan q = make_plan(s);
+            S256_LGKM0();
+            S256_FENCE();              // nothing to wait for: the only vector-memory operations in flight are Elo's stores
+            stamp();
+            S256_BARRIER();
+            stamp();
+            mfma_half(integral_constant<int, H_FIRST_LO>{}, q, qprev);
+            stamp();
+            S256_BARRIER();
+            stamp();
+            if (s > 0) epilogue(s - 1, 1);
+            read_hi(s);
+            S256_LGKM0();
+            if (s > 0 && stores16) S256_VMCNT(8); else S256_VMCNT(0);
+            stamp();
+            S256_BARRIER();
+            stamp();
+            mfma_half(integral_constant<int, H_FIRST_HI>{}, q, qprev);
+            stamp();
+            S256_BARRIER();
+            ++s;
+        }
+        for (int kt = 1; kt < nk - 1; ++kt, ++s) {
+            // ======== middle K-steps: R | M (as gemm16_s256.hip) ========
+            read_step(s);
+            const Plan q = make_plan(s);
+            S256_LGKM0();
+            S256_VMCNT(0);
+            stamp();
+            S256_BARRIER();
+            stamp();
+            mfma_step(q, false);
+            stamp();
+            S256_BARRIER();
+        }
+        {
+            // ======== last K-step of a tile: Rlo | Mlo | Rhi + Elo | Mhi ========
+            read_lo(s);
+            const Plan q = make_plan(s);
+            S256_LGKM0();
+            S256_VMCNT(0);             // the pieces of M(s-1) (after a first step: Ehi's stores too, two slots old)
+            stamp();
+            S256_BARRIER();
+            stamp();
+            mfma_half(integral_constant<int, H_LAST_LO>{}, q, qprev);
+            stamp();
+            S256_BARRIER();
+            stamp();
+            epilogue(s, 0);
+            read_hi(s);
+            S256_LGKM0();
+            if (stores16) S256_VMCNT(8); else S256_VMCNT(0);
+            stamp();
+            S256_BARRIER();
+            stamp();
+            mfma_half(integral_constant<int, H_LAST_HI>{}, q, qprev);
+            stamp();
+            S256_BARRIER();
+            qprev = q;
+            ++s;
+        }
+    }
+    epilogue(nsteps - 1, 1);           // the last tile's hi rows
+    if (grp == 0) S256_BARRIER();      // matches B's last slot
+#ifdef S256_TIMELINE
+    if (dbg_on && lane == 0)
+        for (int i = 0; i < 1024; ++i) ((unsigned*)p.out)[8192 + grp * 1024 + i] = sStamp[i];
+#endif
+    // The plan is unconditional, so the last MFMA slots issued LDS-DMA loads nobody reads: they must have landed before
+    // this workgroup's LDS can be handed to another workgroup.
+    S256_VMCNT(0);
+    if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
+        ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
+        ((long long*)p.out)[2 * blockIdx.x + 1] = nsteps;
+    }
+}
+
+template <typename T, int EPI>
+int launch_epi(const Gemm16Args& a, hipStream_t s) {
+    static OncePerDevice attr;
+    auto kern = gemm16_h256_kernel<T, EPI>;
+    if (attr.first())
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S_STAGE_BYTES + 8192 * 4));
+    const int tiles_m = (int)ceil_div(a.M, SBM), tiles_n = a.N / SBN;
+    const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+    const int cus = iisan_cu_count();
+    int grid = (int)(ntiles < cus ? ntiles : cus);
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * S_STAGE_BYTES + (size_t)a.N * 4 + ((a.debug & 16) ? 8192 : 0), s, a, tiles_m, tiles_n);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+template <typename T>
+int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
+    switch (mode) {
+        case EPI_OUT16: return launch_epi<T, EPI_OUT16>(a, s);
+        case EPI_GELU16: return launch_epi<T, EPI_GELU16>(a, s);
+        case EPI_QKVH16: return launch_epi<T, EPI_QKVH16>(a, s);
+        default: iisan_set_error("gemm16_s256: epilogue mode %d not supported", mode); return IISAN_EBADSHAPE;
+    }
+}
+
+}  // namespace
+
+bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
+    return (mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16) && a.N % SBN == 0 && a.N <= 8192 && a.K % SBK == 0 &&
+           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31);
+}
+
+int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
+    return dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+}

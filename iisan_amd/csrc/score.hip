@@ -2,66 +2,178 @@
 // Replaces the per-user Python loop of eval_model + the full argsort of metrics_topK
 // (Code_Uncached/data_utils/metrics.py:59-67,198-207): scores = prec · item_emb^T, history -> -inf, column 0
 // dropped, rank = 1 + #{items ahead of the target}.  Ties are resolved towards the lower item id (the reference's
-// argsort leaves tie order unspecified).  HBM/L2-bound: the item table ([n,64] fp32, 5 MB for
-// Scientific) is streamed once per user block from L2; integer-exact counting, no sort.
+// argsort leaves tie order unspecified).  Integer-exact counting, no sort, the [U, N] scores never exist.
+//
+// Round 3: the score product runs on the f32 matrix cores (`v_mfma_f32_16x16x4_f32`, exact fp32 FMAs), 32 users per
+// workgroup.  The first version gave every user its own workgroup whose 256 threads each streamed whole 256-byte item rows:
+// the 5.2 MB table was re-read from L2 once per USER (62.8 GB per Scientific eval pass) and every score was a 64-step
+// dependent VALU chain.  Now a workgroup holds the user vectors of 32 users as B fragments in registers (loop invariant),
+// its four waves walk disjoint 16-item tiles (A fragments: 64 contiguous bytes per lane and tile, next tile prefetched),
+// and one item-row load feeds two MFMAs: the table is read once per 32 users (1.9 GB) and item splits across blockIdx.y
+// fill the chip, partial counts meeting in `ranks` through integer atomics (exact, order-free).
+//
+// Exactness: a rank is a count of comparisons `score(c) > score(target)`; every score of a user — the target's, its history
+// items', every other item's — comes out of the SAME 16-MFMA chain with the same contraction order (lane group g contracts
+// k = 16g .. 16g+15; the four groups meet in the MFMA's own fixed reduction), so equal inputs give equal bits wherever the
+// item sits in a tile.  The target's and the history items' scores are taken from the diagonal of extra tiles whose row i
+// is "the h-th item of user i".  History: a history item contributes with score -inf instead of its raw score; if the
+// target itself is in the history its score is -inf as well (metrics.py:204-205: reproduced, not fixed).
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ float dot64(const float* __restrict__ a, const float* p) {
-    float s = 0.f;
+constexpr int UB = 32;          // users per workgroup (two 16-user B fragment sets)
+constexpr int MAXH = 64;        // history entries per user handled on the device path
+
+__device__ __forceinline__ bool ahead(float s, int c, float st, int t) { return s > st || (s == st && c < t); }
+
+// one 16-item tile against both user sets: acc[u][r] = score(item 4*(lane/16) + r of the tile, user 16u + lane%16)
+__device__ __forceinline__ void tile_scores(const f4 (&a)[4], const f4 (&b)[2][4], f4 (&acc)[2]) {
+    acc[0] = (f4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const f4 t = *(const f4*)(a + 4 * v);
-        s = fmaf(t[0], p[4 * v], s);
-        s = fmaf(t[1], p[4 * v + 1], s);
-        s = fmaf(t[2], p[4 * v + 2], s);
-        s = fmaf(t[3], p[4 * v + 3], s);
-    }
-    return s;
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v][e], b[0][v][e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v][e], b[1][v][e], acc[1], 0, 0, 0);
+        }
 }
 
-__device__ __forceinline__ bool ahead(float s, int64_t c, float st, int64_t t) { return s > st || (s == st && c < t); }
-
-__global__ __launch_bounds__(256) void score_rank_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb,
-                                                         int64_t n_items, const int32_t* __restrict__ history, int hist_stride,
-                                                         const int32_t* __restrict__ target, int32_t* __restrict__ ranks) {
-    __shared__ float sp[64];
-    __shared__ int red[256];
-    const int64_t u = blockIdx.x;
-    if (threadIdx.x < 64) sp[threadIdx.x] = prec[u * 64 + threadIdx.x];
-    __syncthreads();
-    float p[64];
+__device__ __forceinline__ void load_row16(const float* __restrict__ row, int g, f4 (&a)[4]) {
 #pragma unroll
-    for (int e = 0; e < 64; ++e) p[e] = sp[e];
-    const int64_t t = target[u];
-    if (t <= 0 || t >= n_items) {            // not an item: never dereferenced, reported as rank -1
-        if (threadIdx.x == 0) ranks[u] = -1;
-        return;
+    for (int v = 0; v < 4; ++v) a[v] = *(const f4*)(row + 16 * g + 4 * v);
+}
+
+__global__ __launch_bounds__(256) void score_rank_mfma_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb,
+                                                              int n_items, const int32_t* __restrict__ history, int hist_stride,
+                                                              const int32_t* __restrict__ target, int32_t* __restrict__ ranks,
+                                                              int U, int tiles_per_split) {
+    __shared__ float s_sc[MAXH + 1][UB];      // [h][user]: raw score of history entry h (h < hist_stride) / of the target (h = hist_stride)
+    __shared__ float s_st[UB];                // the target's effective score (-inf when it is in the history)
+    __shared__ int s_t[UB];                   // target id (0 = invalid: rank -1)
+    __shared__ int s_cnt[UB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int u0 = blockIdx.x * UB;
+
+    // the users' vectors as B fragments: lane (j, g) holds prec[u0 + 16u + j][16g .. 16g+15]
+    f4 b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int uu = u0 + 16 * u + j;
+        if (uu < U) load_row16(prec + (int64_t)uu * 64, g, b[u]);
+        else
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
     }
-    const int32_t* hist = history + u * hist_stride;
-    bool t_in_hist = false;
-    for (int h = 0; h < hist_stride; ++h) t_in_hist |= (hist[h] == (int32_t)t && hist[h] != 0);
-    const float st = t_in_hist ? -INFINITY : dot64(item_emb + t * 64, p);
-    int cnt = 0;
-    for (int64_t c = 1 + threadIdx.x; c < n_items; c += 256) cnt += ahead(dot64(item_emb + c * 64, p), c, st, t) ? 1 : 0;
-    // history corrections: a history item contributes with score -inf instead of its raw score
-    for (int h = threadIdx.x; h < hist_stride; h += 256) {
-        const int64_t c = hist[h];
-        if (c <= 0 || c >= n_items) continue;
-        bool dup = false;
-        for (int k = 0; k < h; ++k) dup |= hist[k] == hist[h];
-        if (dup) continue;
-        if (ahead(dot64(item_emb + c * 64, p), c, st, t)) cnt -= 1;
-        if (ahead(-INFINITY, c, st, t)) cnt += 1;
+    if (threadIdx.x < UB) {
+        const int uu = u0 + (int)threadIdx.x;
+        int t = uu < U ? target[uu] : 0;
+        if (t <= 0 || t >= n_items) t = 0;                // not an item: never dereferenced, reported as rank -1
+        s_t[threadIdx.x] = t;
+        s_cnt[threadIdx.x] = 0;
     }
-    red[threadIdx.x] = cnt;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+
+    // ---- phase 1: raw scores of every user's target and history items (diagonals of gathered tiles), tiles spread over the waves.
+    // Tile (h, half): row i = entry h of user u0 + 16*half + i; only the user set `half` is of interest.
+    const int n_ent = hist_stride + 1;
+    for (int e = wave; e < 2 * n_ent; e += 4) {
+        const int h = e >> 1, half = e & 1;
+        const int uu = u0 + 16 * half + j;               // row j of the tile belongs to this user
+        int c = 0;
+        if (uu < U) c = h < hist_stride ? history[(int64_t)uu * hist_stride + h] : s_t[16 * half + j];
+        if (c < 0 || c >= n_items) c = 0;
+        f4 a[4], acc[2];
+        load_row16(item_emb + (int64_t)c * 64, g, a);
+        tile_scores(a, b, acc);
+        // D[i][jj] sits in lane (jj, i / 4), element i % 4: the diagonal i == jj
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r == j) s_sc[h][16 * half + j] = half ? acc[1][r] : acc[0][r];
     }
-    if (threadIdx.x == 0) ranks[u] = 1 + red[0];
+    __syncthreads();
+    if (threadIdx.x < UB) {
+        const int x = threadIdx.x, uu = u0 + x, t = s_t[x];
+        bool in_hist = false;
+        if (uu < U && t > 0)
+            for (int h = 0; h < hist_stride; ++h) in_hist |= history[(int64_t)uu * hist_stride + h] == t;
+        s_st[x] = in_hist ? -INFINITY : s_sc[hist_stride][x];
+    }
+    __syncthreads();
+
+    // ---- phase 2: count the items ahead of the target over this workgroup's item range
+    float st[2]; int tt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { st[u] = s_st[16 * u + j]; tt[u] = s_t[16 * u + j]; }
+    const int n_tiles = (n_items + 15) >> 4;
+    const int tile_lo = blockIdx.y * tiles_per_split;
+    int tile_hi = tile_lo + tiles_per_split;
+    if (tile_hi > n_tiles) tile_hi = n_tiles;
+    int cnt[2] = {0, 0};
+    f4 a[4], an[4];
+    int tile = tile_lo + wave;
+    auto row_of = [&](int tl) { int c = tl * 16 + j; return item_emb + (int64_t)(c < n_items ? c : 0) * 64; };
+    if (tile < tile_hi) load_row16(row_of(tile), g, a);
+    for (; tile < tile_hi; tile += 4) {
+        const bool more = tile + 4 < tile_hi;
+        if (more) load_row16(row_of(tile + 4), g, an);          // next tile's rows in flight during this tile's MFMAs
+        f4 acc[2];
+        tile_scores(a, b, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = tile * 16 + 4 * g + r;
+            const bool item = c >= 1 && c < n_items;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) cnt[u] += (item && c != tt[u] && ahead(acc[u][r], c, st[u], tt[u])) ? 1 : 0;
+        }
+        if (more)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[v] = an[v];
+    }
+    // lanes (j, g = 0..3) hold partial counts of the same user
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        cnt[u] += __shfl_xor(cnt[u], 16, 64);
+        cnt[u] += __shfl_xor(cnt[u], 32, 64);
+        if (g == 0 && cnt[u]) atomicAdd(&s_cnt[16 * u + j], cnt[u]);
+    }
+    __syncthreads();
+
+    // ---- phase 3: history corrections (first item split only) and the result
+    if (threadIdx.x < UB) {
+        const int x = threadIdx.x, uu = u0 + x;
+        if (uu >= U) return;
+        const int t = s_t[x];
+        if (t == 0) {
+            if (blockIdx.y == 0) ranks[uu] = -1;          // the launch zeroes `ranks` first; the other splits add nothing
+            return;
+        }
+        int c_all = s_cnt[x];
+        if (blockIdx.y == 0) {
+            const float stx = s_st[x];
+            const int32_t* hist = history + (int64_t)uu * hist_stride;
+            for (int h = 0; h < hist_stride; ++h) {
+                const int c = hist[h];
+                if (c <= 0 || c >= n_items || c == t) continue;
+                bool dup = false;
+                for (int k = 0; k < h; ++k) dup |= hist[k] == c;
+                if (dup) continue;
+                if (ahead(s_sc[h][x], c, stx, t)) c_all -= 1;         // counted above with its raw score ...
+                if (ahead(-INFINITY, c, stx, t)) c_all += 1;          // ... but it scores -inf
+            }
+            c_all += 1;                                               // rank = 1 + #ahead
+        }
+        if (c_all) atomicAdd(&ranks[uu], c_all);
+    }
+}
+
+// invalid targets: a split other than 0 must not add to the -1 another block wrote; handled by giving those users no count
+// (t == 0 returns before the atomic) — so `ranks` only needs zeroing before the launch.
+__global__ void zero_ranks_kernel(int32_t* __restrict__ r, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = 0;
 }
 
 }  // namespace
@@ -69,10 +181,24 @@ __global__ __launch_bounds__(256) void score_rank_kernel(const float* __restrict
 extern "C" int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
                                 const int32_t* history, int32_t hist_stride, const int32_t* target, int32_t* ranks,
                                 void* stream) {
+    hipStream_t s = (hipStream_t)stream;
     IISAN_CHECK_SHAPE(E == 64, "score_rank: embedding_dim must be 64 (got %d)", E);
     IISAN_CHECK_SHAPE(U > 0 && n_items_plus1 > 1 && hist_stride >= 0, "score_rank: empty problem");
-    hipLaunchKernelGGL(score_rank_kernel, dim3((unsigned)U), dim3(256), 0, (hipStream_t)stream, prec, item_emb, n_items_plus1,
-                       history, hist_stride, target, ranks);
+    IISAN_CHECK_SHAPE(hist_stride <= MAXH, "score_rank: at most %d history entries per user (got %d)", MAXH, hist_stride);
+    IISAN_CHECK_SHAPE(U < (1ll << 31) - UB && n_items_plus1 < (1ll << 31) - 16, "score_rank: problem too large for 32-bit indices");
+    IISAN_CHECK_SHAPE((((uintptr_t)prec | (uintptr_t)item_emb) & 15) == 0, "score_rank: prec and item_emb must be 16-byte aligned");
+    const int ublocks = (int)ceil_div(U, UB);
+    const int n_tiles = (int)ceil_div(n_items_plus1, 16);
+    // item splits: about four workgroups per CU in total, at least 16 tiles (4 per wave) each
+    int splits = (int)ceil_div((int64_t)4 * iisan_cu_count(), ublocks);
+    if (splits > n_tiles / 16) splits = n_tiles / 16;
+    if (splits < 1) splits = 1;
+    const int per = (int)ceil_div(n_tiles, splits);
+    splits = (int)ceil_div(n_tiles, per);
+    hipLaunchKernelGGL(zero_ranks_kernel, dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, s, ranks, U);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(score_rank_mfma_kernel, dim3((unsigned)ublocks, (unsigned)splits), dim3(256), 0, s, prec, item_emb,
+                       (int)n_items_plus1, history, hist_stride, target, ranks, (int)U, per);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

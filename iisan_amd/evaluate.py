@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import dp, ops
@@ -55,19 +56,37 @@ def item_table(model, images_or_taps: torch.Tensor, text_or_taps: torch.Tensor, 
     return dp.gather_concat(pad, per * world)[:N]
 
 
-def _pack_users(seqs: Sequence[Sequence[int]], max_seq_len: int, hist_stride: int):
-    """Left-padded history tokens / masks (BuildMMEvalDataset, dataset.py:183-189), 0-padded history list, targets."""
+def _ragged(rows, n):
+    """(flat int64 array, lengths, end offsets) of a list of n integer sequences."""
+    import itertools
+    lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=n)
+    flat = np.fromiter(itertools.chain.from_iterable(rows), dtype=np.int64, count=int(lens.sum()))
+    return flat, lens, np.cumsum(lens)
+
+
+def _pack_users(seqs: Sequence[Sequence[int]], histories: Sequence[Sequence[int]], max_seq_len: int, hist_stride: int):
+    """Left-padded history tokens / masks (BuildMMEvalDataset, dataset.py:183-189), 0-padded exclusion lists, targets.
+    Vectorised: the per-user Python loop of the first version (two tensor constructions per user) was 95 % of an eval pass
+    at Scientific size (12,076 users: 200 ms around 8 ms of device work)."""
     U = len(seqs)
-    tok = torch.zeros(U, max_seq_len, dtype=torch.int64)
-    lm = torch.zeros(U, max_seq_len)
-    hist = torch.zeros(U, hist_stride, dtype=torch.int32)
-    tgt = torch.zeros(U, dtype=torch.int32)
-    for u, seq in enumerate(seqs):
-        t = list(seq[:-1])[-max_seq_len:]
-        tok[u, max_seq_len - len(t):] = torch.tensor(t, dtype=torch.int64)
-        lm[u, max_seq_len - len(t):] = 1
-        tgt[u] = seq[-1]
-    return tok, lm, hist, tgt
+    flat, lens, ends = _ragged(seqs, U)
+    if U and int(lens.min()) < 1:
+        raise ValueError("evaluate_ranks: every eval sequence needs at least its target item")
+    tgt = flat[ends - 1] if U else np.zeros(0, np.int64)
+    hl = np.minimum(lens - 1, max_seq_len)                           # history positions that fit the window
+    tok = np.zeros((U, max_seq_len), dtype=np.int64)
+    lm = np.zeros((U, max_seq_len), dtype=np.float32)
+    rows = np.repeat(np.arange(U), hl)
+    k = np.arange(int(hl.sum())) - np.repeat(np.cumsum(hl) - hl, hl)  # 0 .. hl[u]-1 within each user
+    col = max_seq_len - hl[rows] + k
+    tok[rows, col] = flat[(ends - 1 - hl)[rows] + k]
+    lm[rows, col] = 1.0
+    hflat, hlens, hends = _ragged(histories, U)
+    hist = np.zeros((U, hist_stride), dtype=np.int32)
+    hrows = np.repeat(np.arange(U), hlens)
+    hk = np.arange(int(hlens.sum())) - np.repeat(hends - hlens, hlens)
+    hist[hrows, hk] = hflat
+    return torch.from_numpy(tok), torch.from_numpy(lm), torch.from_numpy(hist), torch.from_numpy(tgt.astype(np.int32))
 
 
 @torch.no_grad()
@@ -78,10 +97,7 @@ def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[i
     U = len(eval_seqs)
     hs = max(1, max(len(h) for h in histories))
     idx = dp.sequential_shard(U, rank, world, batch) if world > 1 else list(range(U))
-    tok, lm, hist, tgt = _pack_users([eval_seqs[i] for i in idx], max_seq_len, hs)
-    for r, i in enumerate(idx):
-        h = torch.tensor(list(histories[i]), dtype=torch.int32)
-        hist[r, :h.numel()] = h
+    tok, lm, hist, tgt = _pack_users([eval_seqs[i] for i in idx], [histories[i] for i in idx], max_seq_len, hs)
     dev = item_emb.device
     was_training = model.training
     model.eval()

@@ -28,7 +28,7 @@ def gemm_variant(lib, request):
     lib.iisan_set_gemm16_variant(0)
 
 
-@pytest.mark.parametrize("gemm_variant", [0, 1, 2, 3], indirect=True)
+@pytest.mark.parametrize("gemm_variant", [0, 1, 2, 3, 4], indirect=True)
 @pytest.mark.parametrize("dt", [_lib.IISAN_F16, _lib.IISAN_BF16])
 def test_full_size_taps_match_reference_golden(dt, gemm_variant):
     """All 13 CLS taps of ViT-B/16 and BERT-base against the taps the REAL reference produced (HF modules,
