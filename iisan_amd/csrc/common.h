@@ -158,31 +158,33 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // pairs so that every Horner / squaring step is 8 INDEPENDENT instructions: with one wave per SIMD doing VALU work the
 // dependent chain of a single evaluation (~8 cycles of latency per step) is otherwise exposed.
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_erf_fast2x8(f2 (&x)[8]) {
-    f2 a[8], p[8];
+template <int NP>
+__device__ __forceinline__ void gelu_erf_fast2xN(f2* x) {
+    f2 a[NP], p[NP];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { a[k][0] = gelu_absmin(x[k][0]); a[k][1] = gelu_absmin(x[k][1]); }
+    for (int k = 0; k < NP; ++k) { a[k][0] = gelu_absmin(x[k][0]); a[k][1] = gelu_absmin(x[k][1]); }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(a[k], (f2)GELU_C5, (f2)GELU_C4);
+    for (int k = 0; k < NP; ++k) p[k] = __builtin_elementwise_fma(a[k], (f2)GELU_C5, (f2)GELU_C4);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C3);
+    for (int k = 0; k < NP; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C3);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C2);
+    for (int k = 0; k < NP; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C2);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C1);
+    for (int k = 0; k < NP; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C1);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C0);
+    for (int k = 0; k < NP; ++k) p[k] = __builtin_elementwise_fma(p[k], a[k], (f2)GELU_C0);
 #pragma unroll
     for (int sq = 0; sq < 3; ++sq)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = p[k] * p[k];
+        for (int k = 0; k < NP; ++k) p[k] = p[k] * p[k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NP; ++k) {
         f2 mx;
         mx[0] = gelu_relu(x[k][0]); mx[1] = gelu_relu(x[k][1]);
         x[k] = __builtin_elementwise_fma(-a[k], p[k], mx);
     }
 }
+__device__ __forceinline__ void gelu_erf_fast2x8(f2 (&x)[8]) { gelu_erf_fast2xN<8>(x); }
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

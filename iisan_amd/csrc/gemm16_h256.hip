@@ -46,6 +46,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int SBM = 256, SBN = 256, SBK = 64;
 constexpr int S_OP_BYTES = SBM * SBK * 2;        // 32 KiB per operand tile
 constexpr int S_STAGE_BYTES = 2 * S_OP_BYTES;    // 64 KiB per K-step
+constexpr int STG_BIAS_BYTES = 4096 * 4;           // LDS after the ring: the layer's bias vector (N <= 4096 floats) ...
+constexpr int STG_TILE_BYTES = 8 * 2048;           // ... and a 2-KiB transposition tile per wave (160 KiB in all)
 
 template <typename T> struct Mfma32s;
 template <> struct Mfma32s<F16> {
@@ -64,18 +66,21 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
         asm volatile("s_barrier" ::: "memory");          \
         S256_FENCE();                                    \
     } while (0)
-#define S256_VMCNT(n)                                        \
-    do {                                                     \
-        S256_FENCE();                                        \
-        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
-        S256_FENCE();                                        \
+// vmcnt(n) / lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14), not inline asm:
+// hipcc's own wait insertion then knows what has retired.  With the asm form it re-waited `vmcnt(0)` at the first touch of a
+// register it had reloaded from scratch slots earlier — in the middle of the epilogue arithmetic, behind the LDS-DMA issued since.
+#define S256_VMCNT(n)                                                                              \
+    do {                                                                                           \
+        S256_FENCE();                                                                              \
+        __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14));  \
+        S256_FENCE();                                                                              \
     } while (0)
-#define S256_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define S256_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0) */
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
     typedef typename T::v8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + N floats of bias
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + 4096 floats of bias + 8 transposition tiles
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
 
@@ -308,80 +313,118 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    bool stores16 = false;     // the last epilogue issued exactly 16 store instructions per wave (full row tile, stores enabled)
-    auto epilogue = [&](int s, int half) {
-        const int ti = s / nk;
-        const int tau = pid + ti * G;
-        const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
-        stores16 = ((int64_t)(tm + 1) * SBM <= p.M) && !(p.debug & 1);
-        // head-major QKV: this wave's 64 columns are one (q|k|v, head) pair -> wave-uniform; (item, token) of a row by
-        // ONE 32-bit division per tile, then advanced by 32 rows per block (a 64-bit division per block cost ~800
-        // VALU instructions per tile and wave)
-        unsigned qk_which = 0, qk_hd = 0, qk_item = 0, qk_tok = 0;
-        const unsigned qk_S = (unsigned)p.qkv_S;
-        if constexpr (EPI == EPI_QKVH16) {
-            const unsigned Dm = (unsigned)p.qkv_heads * 64u, n64 = (unsigned)(tn * SBN + wq * 64);
-            const unsigned wq_ = n64 / Dm;
-            qk_hd = (n64 - wq_ * Dm) >> 6;
-            qk_which = wq_ + (unsigned)p.qkv_which0;
-            const unsigned m0 = (unsigned)(tm * SBM + grp * 128 + half * 64 + frow);
-            qk_item = m0 / qk_S;
-            qk_tok = m0 - qk_item * qk_S;
-        }
-        // the lane's 32 bias values (its columns are the same for every 32-row block) are read from LDS ONCE per epilogue
-        // half, up front — read inside the block loop, each block's four reads sat right before their adds behind an
-        // lgkmcnt(0) (ISA): eight exposed LDS round trips per epilogue half
-        f4 bbv[2][4];
+    bool stores8 = false;      // the last epi_store issued exactly 8 store instructions per wave (full row tile, stores enabled)
+    // ---- epilogue of one half (rows half*64 .. +63 of the group's 128: acc[2*half .. 2*half+1][*]) of a tile, in two stages:
+    //   epi_arith : bias (+ GELU), 16-bit convert, and the transposition of the four 32 x 32 blocks through a wave-private
+    //               2-KiB LDS tile into `pend` (32 registers);
+    //   epi_store : the eight 16-byte global stores of `pend`.
+    // What the slot timelines (tools/gemm_slots_h.py) showed on the way here.  The s256 epilogue inside a half-slot: a [Rhi + E]
+    // slot of 2,650-3,400 cycles beside a 700-cycle sibling MFMA slot — arithmetic alone 2,350 (three integer divisions for the
+    // tile / QKV row coordinates, 64-bit per-lane address products, per-lane row tests with exec masking, branch-guarded bias
+    // reads), stores alone 2,650-3,000 (one 16-byte piece per lane in 64 different rows: the addresser takes one such piece per
+    // cycle, 64 cycles per instruction x 8 x the 4 waves of a group).  With incremental tile coordinates, reciprocal
+    // multiplication, wave-uniform store bases and LDS-transposed stores (four adjacent lanes = 64 contiguous bytes: 16 cycles
+    // per instruction): 2,100 — arithmetic 1,350 of it (packed f32 adds next to the sibling's MFMAs are slow, MI355X_MICROARCH:
+    // "an anti-lever beside MFMAs"), the block-by-block LDS round trips 870, the stores 420.  Hence: scalar adds and all four
+    // blocks' LDS traffic back to back with one wait.
+    // LDS tile: row r at r*64, its four 16-byte chunks XOR-swizzled with (r >> 1) & 3 — conflict-free for the eight-lane
+    // groups of `ds_write_b128` and the sixteen-lane groups of `ds_read_b128` (MI355X_MICROARCH.md, LDS table).  One wave's
+    // LDS operations execute in order: block b+1's writes cannot overtake block b's read-back.
+    char* const stg = smem + 2 * S_STAGE_BYTES + STG_BIAS_BYTES + wave * 2048;
+    V8 pend[4][2];             // block b = (mi & 1) + 2 * ni of the half; [rr]: rows 16 rr + lane / 4, columns 8 (lane & 3) .. +7 of the block
+    auto epi_arith = [&](int tn, int half) {
+        // The lane-dependent offsets are RECOMPUTED here from a laundered lane id (a dozen VALU instructions): hoisted out of
+        // the K loop they stay live across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is
+        // followed by an `s_waitcnt vmcnt(0)` — which also waits for the LDS-DMA in flight and the stores.
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int frow = l2 & 31, fh = l2 >> 5;
+        const uint32_t stg_w0 = (uint32_t)(frow * 64 + (((2 * fh) ^ ((frow >> 1) & 3)) << 4));          // this lane's chunk 2*fh
+        const uint32_t stg_w1 = (uint32_t)(frow * 64 + (((2 * fh + 1) ^ ((frow >> 1) & 3)) << 4));      // ... and 2*fh + 1
+        const uint32_t stg_r = (uint32_t)((l2 >> 2) * 64 + (((l2 & 3) ^ ((l2 >> 3) & 3)) << 4));        // read-back: row l2/4 (+16 rr), chunk l2&3
+        const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
+        if (p.debug & 1) return;
+        f4 bbv[4];             // the lane's 16 bias values of column block ni (the same for every 32-row block)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int b = 0; b < 4; ++b) {
+            const int mi = 2 * half + (b & 1), ni = b >> 1;
+            if ((b & 1) == 0) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                bbv[ni][q4] = p.bias ? *(const f4*)(sBias + tn * SBN + wq * 64 + ni * 32 + 16 * fh + 4 * q4) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            if ((mi >> 1) != half) continue;
-            const int64_t m = (int64_t)tm * SBM + grp * 128 + mi * 32 + frow;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int n = tn * SBN + wq * 64 + ni * 32 + 16 * fh;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
-                if (m >= p.M || (p.debug & 1)) continue;
-
-                typename T::elem* op;
-                if constexpr (EPI == EPI_QKVH16) {
-                    op = (typename T::elem*)p.out + ((((int64_t)qk_item * p.qkv_heads + qk_hd) * 3 + qk_which) * qk_S + qk_tok) * 64 + (ni * 32 + 16 * fh);
-                } else {
-                    op = (typename T::elem*)p.out + m * p.ldo + n;
-                }
-                f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) g[k] = (f2){v[2 * k], v[2 * k + 1]} + (f2){bbv[ni][k >> 1][2 * (k & 1)], bbv[ni][k >> 1][2 * (k & 1) + 1]};
-                if constexpr (EPI == EPI_GELU16) gelu_erf_fast2x8(g);
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    V8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        o[e] = T::from_f32(g[4 * h2 + e / 2][0]);
-                        o[e + 1] = T::from_f32(g[4 * h2 + e / 2][1]);
-                    }
-                    *(V8*)(op + 8 * h2) = o;
-                }
+                for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
             }
-            if constexpr (EPI == EPI_QKVH16) {
-                qk_tok += 32;
-                while (qk_tok >= qk_S) { qk_tok -= qk_S; ++qk_item; }
+            f2 g[8];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {         // scalar v_add_f32 (asm: -O3 would pack adjacent adds into v_pk_add_f32)
+                float r;
+                asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(acc[mi][ni][k]), "v"(bbv[k >> 2][k & 3]));
+                g[k >> 1][k & 1] = r;
             }
+            // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live across
+            //  this slot, and spilled)
+            if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
+            V8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
+                o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
+            }
+#ifdef S256_TIMELINE
+            if (p.debug & 64) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
+#endif
+            *(V8*)(stg + stg_w0) = o0;
+            *(V8*)(stg + stg_w1) = o1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) pend[b][rr] = *(const V8*)(stg + rr * 1024 + stg_r);
         }
-        // the accumulators are dead now (the next K-step is a tile's first and starts from C = 0); an empty asm that
-        // "defines" them tells the register allocator so — otherwise it copies all 128 of them before the bias add
+        // the accumulators are dead now (the next K-step on them is a tile's first and starts from C = 0); an empty asm that
+        // "defines" them tells the register allocator so — otherwise it copies them before the bias add
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
+    };
+    auto epi_store = [&](int tm, int tn, int half) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int lrow = l2 >> 2, lch = l2 & 3;
+        const bool full = (int64_t)(tm + 1) * SBM <= p.M;
+        stores8 = full && !(p.debug & (1 | 32 | 64));
+        if (p.debug & (1 | 32 | 64)) return;
+        const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
+        const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
+        auto run = [&](auto FULL_T) {                          // FULL (compile time): no row test
+            constexpr bool FULL = decltype(FULL_T)::value;
+            if constexpr (EPI == EPI_QKVH16) {
+                // head-major QKV [item][head][q|k|v][token][64]: this wave's 64 columns are one (q|k|v, head) pair; element-row
+                // index of row m: R = item * (3 heads - 1) S + m + (3 head + which) S,  item = m / S by reciprocal multiplication
+                const uint32_t qk_S = (uint32_t)p.qkv_S, qk_istride = (uint32_t)(3 * p.qkv_heads - 1) * qk_S;
+                const uint32_t Dm = (uint32_t)p.qkv_heads * 64u, n64 = (uint32_t)col0;
+                const uint32_t wq_ = n64 >= 2 * Dm ? 2u : (n64 >= Dm ? 1u : 0u);
+                const uint32_t qk_rowadd = (((n64 - wq_ * Dm) >> 6) * 3u + wq_ + (uint32_t)p.qkv_which0) * qk_S;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uint32_t m = (uint32_t)(row0 + (2 * half + (b & 1)) * 32 + 16 * rr + lrow);
+                        const uint32_t item = __umulhi(m, qkv_magic);        // m / S (exact: m * S < 2^32, checked by the launcher)
+                        const uint32_t R = item * qk_istride + m + qk_rowadd;
+                        char* op = (char*)p.out + ((uint32_t)(R * 128u) + (uint32_t)((b >> 1) * 64 + lch * 16));
+                        if (FULL || (int64_t)m < p.M) *(V8*)op = pend[b][rr];
+                    }
+            } else {
+                const uint32_t out_lane = (uint32_t)(lrow * p.ldo * 2 + lch * 16);      // byte offset of the lane's piece in a 16-row store
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int mrow = row0 + (2 * half + (b & 1)) * 32 + 16 * rr;    // (wave-uniform) first of the 16 rows of this store
+                        char* base = (char*)p.out + ((int64_t)mrow * p.ldo + col0 + (b >> 1) * 32) * 2;
+                        if (FULL || (int64_t)(mrow + lrow) < p.M) *(V8*)(base + out_lane) = pend[b][rr];
+                    }
+            }
+        };
+        if (full) run(std::true_type{}); else run(std::false_type{});
     };
 
     const long long dbg_t0 = __builtin_readcyclecounter();
@@ -389,11 +432,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // at slot boundaries into LDS, dumped to out[] at the end; tools/gemm_slots.py prints the timeline.  Compiled out by
     // default: even the disabled checks cost ~5 % (everything between MFMAs does).
 #ifdef S256_TIMELINE
-    unsigned* sStamp = (unsigned*)(smem + 2 * S_STAGE_BYTES + p.N * 4) + grp * 1024;
+    unsigned* sStamp = (unsigned*)(smem + 2 * S_STAGE_BYTES + STG_BIAS_BYTES - 4096) + grp * 512;     // (timeline builds: the last 4 KiB of the bias area, N <= 3072)
     int dbg_n = 0;
     const bool dbg_on = (p.debug & 16) && blockIdx.x == 0 && wq == 0;
     auto stamp = [&]() {
-        if (dbg_on && dbg_n < 1024) {
+        if (dbg_on && dbg_n < 512) {
             if (lane == 0) sStamp[dbg_n] = (unsigned)(__builtin_readcyclecounter() - dbg_t0);
             ++dbg_n;
         }
@@ -409,8 +452,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         const int units = (int)(blockIdx.x & 7) * nk * ((p.debug >> 8) & 15) / 12;     // (debug>>8)&15 kilo-cycles per XCD at K=768
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
-    if (p.bias)
-        for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias[i];
+    for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias ? p.bias[i] : 0.f;
     __syncthreads();
 
     // ---- prologue: what the steady-state rules would have issued before slot 0 ----
@@ -436,14 +478,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // loads the wait is for: `vmcnt(8)` lets them fly on.
     using std::integral_constant;
     Plan qprev = make_plan(-1);        // pieces 4..7: what the prologue loaded for step 1 (re-issued identically at s = 0)
+    // tile coordinates of the tile being computed and of the one before it, carried incrementally (tile index += G per tile)
+    const int dG_m = G / tiles_n, dG_n = G - dG_m * tiles_n;
+    int cur_tm = pid / tiles_n, cur_tn = pid - cur_tm * tiles_n, prev_tm = 0, prev_tn = 0;
     if (grp == 1) S256_BARRIER();      // B: slot 0 (A is in Rlo(0))
     for (int s = 0; s < nsteps;) {
         {
-            // ======== first K-step of a tile: Rlo | Mlo | Rhi + Ehi(previous tile) | Mhi ========
+            // ======== first K-step of a tile: Rlo | Mlo | Rhi + E(hi, previous tile) | Mhi ========
             read_lo(s);
             const Plan q = make_plan(s);
             S256_LGKM0();
-            S256_FENCE();              // nothing to wait for: the only vector-memory operations in flight are Elo's stores
+            S256_FENCE();              // nothing to wait for: the only vector-memory operations in flight are stores
             stamp();
             S256_BARRIER();
             stamp();
@@ -451,10 +496,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            if (s > 0) epilogue(s - 1, 1);
+            if (s > 0) epi_arith(prev_tn, 1);
             read_hi(s);
+            if (s > 0) epi_store(prev_tm, prev_tn, 1);
             S256_LGKM0();
-            if (s > 0 && stores16) S256_VMCNT(8); else S256_VMCNT(0);
+            // the 8 pieces of Mlo (and, older, the 8 stores of the lo half); the 8 stores just issued stay in flight
+            if (s > 0 && stores8) S256_VMCNT(8); else S256_VMCNT(0);
             stamp();
             S256_BARRIER();
             stamp();
@@ -468,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             read_step(s);
             const Plan q = make_plan(s);
             S256_LGKM0();
-            S256_VMCNT(0);
+            S256_VMCNT(0);             // the pieces of the previous MFMA slot (after a first step: the hi half's stores too, two slots old)
             stamp();
             S256_BARRIER();
             stamp();
@@ -477,11 +524,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             S256_BARRIER();
         }
         {
-            // ======== last K-step of a tile: Rlo | Mlo | Rhi + Elo | Mhi ========
+            // ======== last K-step of a tile: Rlo | Mlo | Rhi + E(lo) | Mhi ========
             read_lo(s);
             const Plan q = make_plan(s);
             S256_LGKM0();
-            S256_VMCNT(0);             // the pieces of M(s-1) (after a first step: Ehi's stores too, two slots old)
+            S256_VMCNT(0);
             stamp();
             S256_BARRIER();
             stamp();
@@ -489,10 +536,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            epilogue(s, 0);
+            epi_arith(cur_tn, 0);
             read_hi(s);
+            epi_store(cur_tm, cur_tn, 0);
             S256_LGKM0();
-            if (stores16) S256_VMCNT(8); else S256_VMCNT(0);
+            if (stores8) S256_VMCNT(8); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
             stamp();
             S256_BARRIER();
             stamp();
@@ -501,13 +549,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             S256_BARRIER();
             qprev = q;
             ++s;
+            prev_tm = cur_tm; prev_tn = cur_tn;
+            cur_tm += dG_m; cur_tn += dG_n;
+            if (cur_tn >= tiles_n) { cur_tn -= tiles_n; ++cur_tm; }
         }
     }
-    epilogue(nsteps - 1, 1);           // the last tile's hi rows
+    epi_arith(prev_tn, 1);             // the last tile's hi rows
+    epi_store(prev_tm, prev_tn, 1);
     if (grp == 0) S256_BARRIER();      // matches B's last slot
 #ifdef S256_TIMELINE
     if (dbg_on && lane == 0)
-        for (int i = 0; i < 1024; ++i) ((unsigned*)p.out)[8192 + grp * 1024 + i] = sStamp[i];
+        for (int i = 0; i < 512; ++i) ((unsigned*)p.out)[8192 + grp * 1024 + i] = sStamp[i];
 #endif
     // The plan is unconditional, so the last MFMA slots issued LDS-DMA loads nobody reads: they must have landed before
     // this workgroup's LDS can be handed to another workgroup.
@@ -522,14 +574,17 @@ template <typename T, int EPI>
 int launch_epi(const Gemm16Args& a, hipStream_t s) {
     static OncePerDevice attr;
     auto kern = gemm16_h256_kernel<T, EPI>;
+    constexpr int LDS = 2 * S_STAGE_BYTES + STG_BIAS_BYTES + STG_TILE_BYTES;       // 160 KiB: the whole LDS of a CU
     if (attr.first())
-        IISAN_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S_STAGE_BYTES + 8192 * 4));
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tiles_m = (int)ceil_div(a.M, SBM), tiles_n = a.N / SBN;
     const int64_t ntiles = (int64_t)tiles_m * tiles_n;
     const int cus = iisan_cu_count();
     int grid = (int)(ntiles < cus ? ntiles : cus);
     grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * S_STAGE_BYTES + (size_t)a.N * 4 + ((a.debug & 16) ? 8192 : 0), s, a, tiles_m, tiles_n);
+    // EPI_QKVH16: item = row / S as one v_mul_hi_u32 by floor(2^32 / S) + 1 — exact while row * S < 2^32 (gemm16_h256_applicable)
+    const uint32_t magic = a.qkv_S > 0 ? (uint32_t)((1ull << 32) / (uint64_t)a.qkv_S) + 1u : 0u;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n, magic);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
@@ -547,8 +602,13 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 }  // namespace
 
 bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
-    return (mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16) && a.N % SBN == 0 && a.N <= 8192 && a.K % SBK == 0 &&
-           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31);
+    if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
+          a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
+        return false;
+    const int64_t rows = ceil_div(a.M, SBM) * SBM;
+    if (mode == EPI_QKVH16)      // 32-bit byte offsets into the head-major tensor, exact reciprocal division
+        return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && rows * (int64_t)(3 - a.qkv_which0) * a.qkv_heads * 128 < (1ll << 32);
+    return (int64_t)a.ldo * 2 * 16 + 64 < (1ll << 31);       // the 32-bit lane offset of a 16-row store
 }
 
 int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
