@@ -46,8 +46,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int SBM = 256, SBN = 256, SBK = 64;
 constexpr int S_OP_BYTES = SBM * SBK * 2;        // 32 KiB per operand tile
 constexpr int S_STAGE_BYTES = 2 * S_OP_BYTES;    // 64 KiB per K-step
-constexpr int STG_BIAS_BYTES = 4096 * 4;           // LDS after the ring: the layer's bias vector (N <= 4096 floats) ...
-constexpr int STG_TILE_BYTES = 8 * 2048;           // ... and a 2-KiB transposition tile per wave (160 KiB in all)
+constexpr int STG_BIAS_BYTES = 8192 * 4;           // LDS after the ring: the layer's bias vector (N <= 8192 floats; 160 KiB in all)
+constexpr int STG_TILE_BYTES = 0;
 
 template <typename T> struct Mfma32s;
 template <> struct Mfma32s<F16> {
@@ -80,7 +80,7 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
     typedef typename T::v8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + 4096 floats of bias + 8 transposition tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + up to 8192 floats of bias
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
 
@@ -313,68 +313,96 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    bool stores8 = false;      // the last epi_store issued exactly 8 store instructions per wave (full row tile, stores enabled)
-    // ---- epilogue of one half (rows half*64 .. +63 of the group's 128: acc[2*half .. 2*half+1][*]) of a tile, in two stages:
-    //   epi_arith : bias (+ GELU), 16-bit convert, and the transposition of the four 32 x 32 blocks through a wave-private
-    //               2-KiB LDS tile into `pend` (32 registers);
-    //   epi_store : the eight 16-byte global stores of `pend`.
-    // What the slot timelines (tools/gemm_slots_h.py) showed on the way here.  The s256 epilogue inside a half-slot: a [Rhi + E]
-    // slot of 2,650-3,400 cycles beside a 700-cycle sibling MFMA slot — arithmetic alone 2,350 (three integer divisions for the
-    // tile / QKV row coordinates, 64-bit per-lane address products, per-lane row tests with exec masking, branch-guarded bias
-    // reads), stores alone 2,650-3,000 (one 16-byte piece per lane in 64 different rows: the addresser takes one such piece per
-    // cycle, 64 cycles per instruction x 8 x the 4 waves of a group).  With incremental tile coordinates, reciprocal
-    // multiplication, wave-uniform store bases and LDS-transposed stores (four adjacent lanes = 64 contiguous bytes: 16 cycles
-    // per instruction): 2,100 — arithmetic 1,350 of it (packed f32 adds next to the sibling's MFMAs are slow, MI355X_MICROARCH:
-    // "an anti-lever beside MFMAs"), the block-by-block LDS round trips 870, the stores 420.  Hence: scalar adds and all four
-    // blocks' LDS traffic back to back with one wait.
-    // LDS tile: row r at r*64, its four 16-byte chunks XOR-swizzled with (r >> 1) & 3 — conflict-free for the eight-lane
-    // groups of `ds_write_b128` and the sixteen-lane groups of `ds_read_b128` (MI355X_MICROARCH.md, LDS table).  One wave's
-    // LDS operations execute in order: block b+1's writes cannot overtake block b's read-back.
-    char* const stg = smem + 2 * S_STAGE_BYTES + STG_BIAS_BYTES + wave * 2048;
-    V8 pend[4][2];             // block b = (mi & 1) + 2 * ni of the half; [rr]: rows 16 rr + lane / 4, columns 8 (lane & 3) .. +7 of the block
-    auto epi_arith = [&](int tn, int half) {
-        // The lane-dependent offsets are RECOMPUTED here from a laundered lane id (a dozen VALU instructions): hoisted out of
-        // the K loop they stay live across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is
-        // followed by an `s_waitcnt vmcnt(0)` — which also waits for the LDS-DMA in flight and the stores.
+    bool stores8 = false;      // the last half-epilogue issued exactly 8 store instructions per wave (full row tile, stores enabled)
+    // ---- half-epilogue: rows half*64 .. +63 of the group's 128 (acc[2*half .. 2*half+1][*]) of tile (tm, tn) ----
+    // What the slot timelines (tools/gemm_slots_h.py, tools/slots_fine.py) showed.  (1) The s256 epilogue inside a half-slot took
+    // 2,650-3,400 cycles beside a 700-cycle sibling MFMA slot; its fixed part — three integer divisions for the tile / QKV row
+    // coordinates, 64-bit per-lane address products, per-lane row tests with exec masking, eight branch-guarded bias reads —
+    // is gone here: tile coordinates are carried incrementally, a QKV row's item is one `v_mul_hi_u32` by a host-computed
+    // reciprocal, stores are a wave-uniform base + one 32-bit lane offset, the bias is always in LDS, full tiles skip the row
+    // test.  (2) WHAT REMAINS IS THE STORE ISSUE RATE OF A CU: one `global_store_dwordx4` wave-instruction per ~92 cycles,
+    // whatever it writes — 8 stores x 4 waves of a group = 2,950 cycles per half-epilogue, the same for one 16-byte piece per
+    // lane in 64 different rows (this layout), for 16 rows x 64 contiguous bytes after an LDS transposition (built, measured,
+    // dropped: the transposition only added 1,600 cycles of LDS time), with the CUs' tile phases spread over a tile time
+    // (debug bit 4: no change — it is not a chip-wide burst limit), and as the guide's T21 note has it ("store-ISSUE-bound, not
+    // bandwidth").  128 store instructions per 256 x 256 tile = 11.8k cycles of a K = 768 tile's ~36k; they overlap the sibling
+    // group's MFMAs only while the accumulators are not needed again, i.e. over the boundary half-slots.
+    // Stores leave block by block, right after their block's arithmetic, so that the queue drains under the next block's.
+    auto epilogue = [&](int tm, int tn, int half) {
+        // The lane-dependent offsets are RECOMPUTED here from a laundered lane id: hoisted out of the K loop they stay live
+        // across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is followed by an
+        // `s_waitcnt vmcnt(0)` — which also waits for the LDS-DMA in flight and the stores.
         int l2 = lane;
         asm volatile("" : "+v"(l2));
         const int frow = l2 & 31, fh = l2 >> 5;
-        const uint32_t stg_w0 = (uint32_t)(frow * 64 + (((2 * fh) ^ ((frow >> 1) & 3)) << 4));          // this lane's chunk 2*fh
-        const uint32_t stg_w1 = (uint32_t)(frow * 64 + (((2 * fh + 1) ^ ((frow >> 1) & 3)) << 4));      // ... and 2*fh + 1
-        const uint32_t stg_r = (uint32_t)((l2 >> 2) * 64 + (((l2 & 3) ^ ((l2 >> 3) & 3)) << 4));        // read-back: row l2/4 (+16 rr), chunk l2&3
+        const bool full = (int64_t)(tm + 1) * SBM <= p.M;
+        stores8 = full && !(p.debug & (1 | 32));
+        const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
         const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
-        if (p.debug & 1) return;
-        f4 bbv[4];             // the lane's 16 bias values of column block ni (the same for every 32-row block)
+        if (!(p.debug & 1)) {
+            auto run = [&](auto FULL_T) {                      // FULL (compile time): no row test
+                constexpr bool FULL = decltype(FULL_T)::value;
+                // byte offset of the lane's 32 bytes (16 columns) inside a 32 x 32 block at (mi, ni)
+                uint32_t lane_off, qk_item0 = 0;
+                uint32_t qk_rowadd = 0, qk_istride = 0;
+                if constexpr (EPI == EPI_QKVH16) {
+                    // head-major QKV [item][head][q|k|v][token][64]: this wave's 64 columns are one (q|k|v, head) pair; element-row
+                    // index of row m: R = item * (3 heads - 1) S + m + (3 head + which) S,  item = m / S by reciprocal multiplication
+                    const uint32_t qk_S = (uint32_t)p.qkv_S;
+                    qk_istride = (uint32_t)(3 * p.qkv_heads - 1) * qk_S;
+                    const uint32_t Dm = (uint32_t)p.qkv_heads * 64u, n64 = (uint32_t)col0;
+                    const uint32_t wq_ = n64 >= 2 * Dm ? 2u : (n64 >= Dm ? 1u : 0u);
+                    qk_rowadd = (((n64 - wq_ * Dm) >> 6) * 3u + wq_ + (uint32_t)p.qkv_which0) * qk_S;
+                    lane_off = (uint32_t)(fh * 32);
+                    (void)qk_item0;
+                } else {
+                    lane_off = (uint32_t)(frow * p.ldo * 2 + fh * 32);
+                }
+                f4 bbv[4];         // the lane's 16 bias values of column block ni (the same for every 32-row block)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int mi = 2 * half + (b & 1), ni = b >> 1;
-            if ((b & 1) == 0) {
+                for (int b = 0; b < 4; ++b) {
+                    const int mi = 2 * half + (b & 1), ni = b >> 1;
+                    if ((b & 1) == 0) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
-            }
-            f2 g[8];
+                        for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
+                    }
+                    f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {         // scalar v_add_f32 (asm: -O3 would pack adjacent adds into v_pk_add_f32)
-                float r;
-                asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(acc[mi][ni][k]), "v"(bbv[k >> 2][k & 3]));
-                g[k >> 1][k & 1] = r;
-            }
-            // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live across
-            //  this slot, and spilled)
-            if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
-            V8 o0, o1;
+                    for (int k = 0; k < 8; ++k)
+                        g[k] = (f2){acc[mi][ni][2 * k], acc[mi][ni][2 * k + 1]} + (f2){bbv[k >> 1][2 * (k & 1)], bbv[k >> 1][2 * (k & 1) + 1]};
+                    // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live
+                    //  across this slot, and spilled)
+                    if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
+                    V8 o0, o1;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
-                o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
-            }
+                    for (int e = 0; e < 8; e += 2) {
+                        o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
+                        o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
+                    }
 #ifdef S256_TIMELINE
-            if (p.debug & 64) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
+                    if (p.debug & 32) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
 #endif
-            *(V8*)(stg + stg_w0) = o0;
-            *(V8*)(stg + stg_w1) = o1;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) pend[b][rr] = *(const V8*)(stg + rr * 1024 + stg_r);
+                    const int mrow = row0 + mi * 32;                       // (wave-uniform) first row of the block
+                    char* op;
+                    bool ok = true;
+                    if constexpr (EPI == EPI_QKVH16) {
+                        const uint32_t m = (uint32_t)(mrow + frow);
+                        const uint32_t item = __umulhi(m, qkv_magic);        // m / S (exact: m * S < 2^32, checked by the launcher)
+                        const uint32_t R = item * qk_istride + m + qk_rowadd;
+                        op = (char*)p.out + ((uint32_t)(R * 128u) + (uint32_t)(ni * 64) + lane_off);
+                        if (!FULL) ok = (int64_t)m < p.M;
+                    } else {
+                        char* base = (char*)p.out + ((int64_t)mrow * p.ldo + col0 + ni * 32) * 2;      // wave-uniform
+                        op = base + lane_off;
+                        if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
+                    }
+                    if (ok) {
+                        *(V8*)op = o0;
+                        *(V8*)(op + 16) = o1;
+                    }
+                }
+            };
+            if (full) run(std::true_type{}); else run(std::false_type{});
         }
         // the accumulators are dead now (the next K-step on them is a tile's first and starts from C = 0); an empty asm that
         // "defines" them tells the register allocator so — otherwise it copies them before the bias add
@@ -383,48 +411,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
-    };
-    auto epi_store = [&](int tm, int tn, int half) {
-        int l2 = lane;
-        asm volatile("" : "+v"(l2));
-        const int lrow = l2 >> 2, lch = l2 & 3;
-        const bool full = (int64_t)(tm + 1) * SBM <= p.M;
-        stores8 = full && !(p.debug & (1 | 32 | 64));
-        if (p.debug & (1 | 32 | 64)) return;
-        const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
-        const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
-        auto run = [&](auto FULL_T) {                          // FULL (compile time): no row test
-            constexpr bool FULL = decltype(FULL_T)::value;
-            if constexpr (EPI == EPI_QKVH16) {
-                // head-major QKV [item][head][q|k|v][token][64]: this wave's 64 columns are one (q|k|v, head) pair; element-row
-                // index of row m: R = item * (3 heads - 1) S + m + (3 head + which) S,  item = m / S by reciprocal multiplication
-                const uint32_t qk_S = (uint32_t)p.qkv_S, qk_istride = (uint32_t)(3 * p.qkv_heads - 1) * qk_S;
-                const uint32_t Dm = (uint32_t)p.qkv_heads * 64u, n64 = (uint32_t)col0;
-                const uint32_t wq_ = n64 >= 2 * Dm ? 2u : (n64 >= Dm ? 1u : 0u);
-                const uint32_t qk_rowadd = (((n64 - wq_ * Dm) >> 6) * 3u + wq_ + (uint32_t)p.qkv_which0) * qk_S;
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const uint32_t m = (uint32_t)(row0 + (2 * half + (b & 1)) * 32 + 16 * rr + lrow);
-                        const uint32_t item = __umulhi(m, qkv_magic);        // m / S (exact: m * S < 2^32, checked by the launcher)
-                        const uint32_t R = item * qk_istride + m + qk_rowadd;
-                        char* op = (char*)p.out + ((uint32_t)(R * 128u) + (uint32_t)((b >> 1) * 64 + lch * 16));
-                        if (FULL || (int64_t)m < p.M) *(V8*)op = pend[b][rr];
-                    }
-            } else {
-                const uint32_t out_lane = (uint32_t)(lrow * p.ldo * 2 + lch * 16);      // byte offset of the lane's piece in a 16-row store
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int mrow = row0 + (2 * half + (b & 1)) * 32 + 16 * rr;    // (wave-uniform) first of the 16 rows of this store
-                        char* base = (char*)p.out + ((int64_t)mrow * p.ldo + col0 + (b >> 1) * 32) * 2;
-                        if (FULL || (int64_t)(mrow + lrow) < p.M) *(V8*)(base + out_lane) = pend[b][rr];
-                    }
-            }
-        };
-        if (full) run(std::true_type{}); else run(std::false_type{});
     };
 
     const long long dbg_t0 = __builtin_readcyclecounter();
@@ -441,8 +427,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             ++dbg_n;
         }
     };
+    auto stamp2 = [&]() {
+#ifdef S256_FINE
+        stamp();
+#endif
+    };
 #else
     auto stamp = [] {};
+    auto stamp2 = [] {};
 #endif
     if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
@@ -496,9 +488,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            if (s > 0) epi_arith(prev_tn, 1);
+            if (s > 0) epilogue(prev_tm, prev_tn, 1);
             read_hi(s);
-            if (s > 0) epi_store(prev_tm, prev_tn, 1);
             S256_LGKM0();
             // the 8 pieces of Mlo (and, older, the 8 stores of the lo half); the 8 stores just issued stay in flight
             if (s > 0 && stores8) S256_VMCNT(8); else S256_VMCNT(0);
@@ -536,9 +527,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            epi_arith(cur_tn, 0);
+            epilogue(cur_tm, cur_tn, 0);
             read_hi(s);
-            epi_store(cur_tm, cur_tn, 0);
             S256_LGKM0();
             if (stores8) S256_VMCNT(8); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
             stamp();
@@ -554,8 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             if (cur_tn >= tiles_n) { cur_tn -= tiles_n; ++cur_tm; }
         }
     }
-    epi_arith(prev_tn, 1);             // the last tile's hi rows
-    epi_store(prev_tm, prev_tn, 1);
+    epilogue(prev_tm, prev_tn, 1);     // the last tile's hi rows
     if (grp == 0) S256_BARRIER();      // matches B's last slot
 #ifdef S256_TIMELINE
     if (dbg_on && lane == 0)
