@@ -451,7 +451,7 @@ class Uncached:
                          # this command with this configuration, profiles/pmc_traffic.json; null for any other configuration)
                          "traffic": pmc_traffic(a) if (headline and dtype == a.dtype and full_blocks == a.full_blocks) else None,
                          "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1),
-                         "kernel": "gemm16 (gemm16_s256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders; flops = executed, by launch)",
+                         "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders; flops = executed, by launch)",
                          "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                          "flop_per_launch": fl.value / max(n_launch, 1),
                          # whole step: GEMM FLOPs actually executed in the timed region / wall time / peak (dead work the

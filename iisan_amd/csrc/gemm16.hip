@@ -254,9 +254,9 @@ int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s
 // Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
 static int g_auto_staggered = 1;
-// auto policy: which staggered kernel takes the production shapes — 1 = gemm16_h256.hip (epilogue hidden in half-slots),
-// 0 = gemm16_s256.hip.  Knob for the same-box A/B (tools/gemm_ab.py).
-static int g_auto_h256 = 0;
+// auto policy: which staggered kernel takes the production shapes — 1 = gemm16_h256.hip (half-slot tile boundary: same-box
+// A/B of tools/gemm_var.py over three boxes: QKV +1..4 %, O +1 %, FC1 +-0, FC2 +3..4 %; bit-identical results), 0 = gemm16_s256.hip.
+static int g_auto_h256 = 1;
 extern "C" void iisan_set_gemm16_h256(int32_t on) { g_auto_h256 = on; }
 // 1: the staggered kernel starts its workgroups up to ~one tile time apart on the short-K products with store-heavy
 // epilogues (QKV scatter, FC1 GELU), so the CUs' store bursts stop coinciding (tools/gemm_time.py: QKV 963 -> 988, FC1 900 ->
