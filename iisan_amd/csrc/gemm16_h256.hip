@@ -46,8 +46,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int SBM = 256, SBN = 256, SBK = 64;
 constexpr int S_OP_BYTES = SBM * SBK * 2;        // 32 KiB per operand tile
 constexpr int S_STAGE_BYTES = 2 * S_OP_BYTES;    // 64 KiB per K-step
-constexpr int STG_BIAS_BYTES = 4096 * 4;           // LDS after the ring: the layer's bias vector (N <= 4096 floats) ...
-constexpr int STG_TILE_BYTES = 8 * 2048;           // ... and a 2-KiB PARKING area per wave: two store instructions' worth (160 KiB in all)
+constexpr int STG_BIAS_BYTES = 8192 * 4;           // LDS after the ring: the layer's bias vector (N <= 8192 floats; 160 KiB in all)
+constexpr int STG_TILE_BYTES = 0;
 
 template <typename T> struct Mfma32s;
 template <> struct Mfma32s<F16> {
@@ -80,7 +80,7 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
     typedef typename T::v8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + up to 4096 floats of bias + 8 parking areas
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + up to 8192 floats of bias
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
 
@@ -313,8 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    bool stores6 = false;      // the last half-epilogue issued exactly 6 store instructions per wave (full row tile, stores enabled)
-    char* const park = smem + 2 * S_STAGE_BYTES + STG_BIAS_BYTES + wave * 2048;
+    bool stores8 = false;      // the last half-epilogue issued exactly 8 store instructions per wave (full row tile, stores enabled)
     // ---- half-epilogue: rows half*64 .. +63 of the group's 128 (acc[2*half .. 2*half+1][*]) of tile (tm, tn) ----
     // What the slot timelines (tools/gemm_slots_h.py, tools/slots_fine.py) showed.  (1) The s256 epilogue inside a half-slot took
     // 2,650-3,400 cycles beside a 700-cycle sibling MFMA slot; its fixed part — three integer divisions for the tile / QKV row
@@ -329,10 +328,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // bandwidth").  128 store instructions per 256 x 256 tile = 11.8k cycles of a K = 768 tile's ~36k; they overlap the sibling
     // group's MFMAs only while the accumulators are not needed again, i.e. over the boundary half-slots.
     // Stores leave block by block, right after their block's arithmetic, so that the queue drains under the next block's.
-    // PARKING: the last block of a half (two of its eight store instructions) is not stored here but written to a wave-private
-    // 2-KiB LDS area and stored one or two read slots LATER by `drain` (lo half: both in the next tile's Rlo; hi half: one each in
-    // the first two middle read slots), where a wave idles at its barrier anyway: 6 x 4 x 92 = 2,200 cycles of store issue per
-    // half-epilogue slot instead of 2,950.
+    // Also built, measured and dropped: PARKING the last block of a half in a wave-private LDS area and storing it one or two read
+    // slots later (6 instead of 8 stores per half-epilogue slot: those slots shrank from 2,700-3,000 to 2,300-2,500 cycles) — the
+    // stores issued from middle read slots then sit in the CU's in-order vector-memory pipeline in front of the LDS-DMA pieces of
+    // the next MFMA slot, which land late: middle slots of 1,500-2,200 cycles appeared and the kernel lost 7 % (QKV 928 against
+    // 998 TFLOP/s).  The vector-memory path (128 stores x 92 + 768 DMA pieces per tile) is as busy as the matrix pipe.
     auto epilogue = [&](int tm, int tn, int half) {
         // The lane-dependent offsets are RECOMPUTED here from a laundered lane id: hoisted out of the K loop they stay live
         // across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is followed by an
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         asm volatile("" : "+v"(l2));
         const int frow = l2 & 31, fh = l2 >> 5;
         const bool full = (int64_t)(tm + 1) * SBM <= p.M;
-        stores6 = full && !(p.debug & (1 | 32));
+        stores8 = full && !(p.debug & (1 | 32));
         const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
         const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
         if (!(p.debug & 1)) {
@@ -401,10 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         op = base + lane_off;
                         if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
                     }
-                    if (b == 3) {          // parked: stored by drain() (same address computation there)
-                        *(V8*)(park + l2 * 16) = o0;
-                        *(V8*)(park + 1024 + l2 * 16) = o1;
-                    } else if (ok) {
+                    if (ok) {
                         *(V8*)op = o0;
                         *(V8*)(op + 16) = o1;
                     }
@@ -419,36 +416,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 if ((mi >> 1) == half) asm volatile("" : "=v"(acc[mi][ni]));
-    };
-
-    // store parked piece j (0 / 1: columns +0..7 / +8..15 of the lane's 16) of block (mi = 2*half + 1, ni = 1) of tile (tm, tn)
-    auto drain = [&](int tm, int tn, int half, int j) {
-        if (p.debug & (1 | 32)) return;
-        int l2 = lane;
-        asm volatile("" : "+v"(l2));
-        const int frow = l2 & 31, fh = l2 >> 5;
-        const bool full = (int64_t)(tm + 1) * SBM <= p.M;
-        const int mrow = tm * SBM + grp * 128 + (2 * half + 1) * 32;          // (wave-uniform) first row of the block
-        const int col0 = tn * SBN + wq * 64;
-        const V8 t = *(const V8*)(park + j * 1024 + l2 * 16);
-        char* op;
-        bool ok;
-        if constexpr (EPI == EPI_QKVH16) {
-            const uint32_t qk_S = (uint32_t)p.qkv_S, qk_istride = (uint32_t)(3 * p.qkv_heads - 1) * qk_S;
-            const uint32_t Dm = (uint32_t)p.qkv_heads * 64u, n64 = (uint32_t)col0;
-            const uint32_t wq_ = n64 >= 2 * Dm ? 2u : (n64 >= Dm ? 1u : 0u);
-            const uint32_t qk_rowadd = (((n64 - wq_ * Dm) >> 6) * 3u + wq_ + (uint32_t)p.qkv_which0) * qk_S;
-            const uint32_t m = (uint32_t)(mrow + frow);
-            const uint32_t item = __umulhi(m, qkv_magic);
-            const uint32_t R = item * qk_istride + m + qk_rowadd;
-            op = (char*)p.out + ((uint32_t)(R * 128u) + (uint32_t)(64 + fh * 32 + j * 16));
-            ok = full || (int64_t)m < p.M;
-        } else {
-            char* base = (char*)p.out + ((int64_t)mrow * p.ldo + col0 + 32) * 2;      // wave-uniform
-            op = base + (uint32_t)(frow * p.ldo * 2 + fh * 32 + j * 16);
-            ok = full || (int64_t)(mrow + frow) < p.M;
-        }
-        if (ok) *(V8*)op = t;
     };
 
     const long long dbg_t0 = __builtin_readcyclecounter();
@@ -512,13 +479,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     const int dG_m = G / tiles_n, dG_n = G - dG_m * tiles_n;
     int cur_tm = pid / tiles_n, cur_tn = pid - cur_tm * tiles_n, prev_tm = 0, prev_tn = 0;
     if (grp == 1) S256_BARRIER();      // B: slot 0 (A is in Rlo(0))
-    bool prev_full = false;            // the previous tile was a full row tile: its drains issue exactly one store instruction each
     for (int s = 0; s < nsteps;) {
         {
-            // ======== first K-step of a tile: Rlo + drain(lo, prev) | Mlo | Rhi + E(hi, prev) | Mhi ========
+            // ======== first K-step of a tile: Rlo | Mlo | Rhi + E(hi, previous tile) | Mhi ========
             read_lo(s);
             const Plan q = make_plan(s);
-            if (s > 0) { drain(prev_tm, prev_tn, 0, 0); drain(prev_tm, prev_tn, 0, 1); }
             S256_LGKM0();
             S256_FENCE();              // nothing to wait for: the only vector-memory operations in flight are stores
             stamp();
@@ -531,8 +496,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             if (s > 0) epilogue(prev_tm, prev_tn, 1);
             read_hi(s);
             S256_LGKM0();
-            // the 8 pieces of Mlo (and, older, the stores of the lo half); the 6 stores just issued stay in flight
-            if (s > 0 && stores6) S256_VMCNT(6); else S256_VMCNT(0);
+            // the 8 pieces of Mlo (and, older, the 8 stores of the lo half); the 8 stores just issued stay in flight
+            if (s > 0 && stores8) S256_VMCNT(8); else S256_VMCNT(0);
             stamp();
             S256_BARRIER();
             stamp();
@@ -542,15 +507,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             ++s;
         }
         for (int kt = 1; kt < nk - 1; ++kt, ++s) {
-            // ======== middle K-steps: R | M (as gemm16_s256.hip); the first two also drain the hi half's parked stores ========
+            // ======== middle K-steps: R | M (as gemm16_s256.hip) ========
             read_step(s);
             const Plan q = make_plan(s);
-            const bool dr = s > nk && kt <= 2;          // (s > nk: not the workgroup's first tile)
-            if (dr) drain(prev_tm, prev_tn, 1, kt - 1);
             S256_LGKM0();
-            // the pieces of the previous MFMA slot (after a first step: the hi half's stores too, two slots old); a drained
-            // store just issued stays in flight
-            if (dr && prev_full) S256_VMCNT(1); else S256_VMCNT(0);
+            S256_VMCNT(0);             // the pieces of the previous MFMA slot (after a first step: the hi half's stores too, two slots old)
             stamp();
             S256_BARRIER();
             stamp();
@@ -574,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             epilogue(cur_tm, cur_tn, 0);
             read_hi(s);
             S256_LGKM0();
-            if (stores6) S256_VMCNT(6); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 6 stores just issued stay in flight
+            if (stores8) S256_VMCNT(8); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
             stamp();
             S256_BARRIER();
             stamp();
@@ -584,16 +545,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             qprev = q;
             ++s;
             prev_tm = cur_tm; prev_tn = cur_tn;
-            prev_full = (int64_t)(prev_tm + 1) * SBM <= p.M && !(p.debug & (1 | 32));
             cur_tm += dG_m; cur_tn += dG_n;
             if (cur_tn >= tiles_n) { cur_tn -= tiles_n; ++cur_tm; }
         }
     }
-    drain(prev_tm, prev_tn, 0, 0);     // the last tile: its lo half's parked stores, the hi half, the hi half's parked stores
-    drain(prev_tm, prev_tn, 0, 1);
-    epilogue(prev_tm, prev_tn, 1);
-    drain(prev_tm, prev_tn, 1, 0);
-    drain(prev_tm, prev_tn, 1, 1);
+    epilogue(prev_tm, prev_tn, 1);     // the last tile's hi rows
     if (grp == 0) S256_BARRIER();      // matches B's last slot
 #ifdef S256_TIMELINE
     if (dbg_on && lane == 0)
@@ -641,7 +597,7 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 
 bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
     if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
-          a.K / SBK >= 4 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
+          a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
         return false;
     const int64_t rows = ceil_div(a.M, SBM) * SBM;
     if (mode == EPI_QKVH16)      // 32-bit byte offsets into the head-major tensor, exact reciprocal division
