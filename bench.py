@@ -95,6 +95,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def check_one_device_per_rank(backend, ranks):
+    """Under backend nccl (RCCL over xGMI) every rank must own its GPU: two ranks that report the same (host, device uuid /
+    index) are a mis-launch, and a line measured that way would be mislabelled — refuse it.  (gloo with every rank on cuda:0
+    is the single-GPU test transport and passes.)"""
+    keys = [(d["host"], d["uuid"] or d["device"]) for d in ranks]
+    if backend == "nccl" and len(set(keys)) != len(ranks):
+        raise SystemExit(f"bench.py: backend nccl (RCCL) with two ranks on one device: {ranks}")
+
+
 class Clock:
     """Barrier + device sync on both sides of the timed region, MAX over ranks (the driver's contract)."""
 
@@ -391,9 +400,7 @@ class Uncached:
         every = [None] * self.world
         dist.all_gather_object(every, mine)
         backend = dist.get_backend()
-        keys = [(d["host"], d["uuid"] or d["device"]) for d in every]
-        if backend == "nccl" and len(set(keys)) != self.world:
-            raise SystemExit(f"bench.py: backend nccl (RCCL) with two ranks on one device: {every}")
+        check_one_device_per_rank(backend, every)
         return {"backend": backend, "world": dist.get_world_size(), "devices": [d["device"] for d in every],
                 "device_uuids": [d["uuid"] for d in every], "hosts": sorted(set(d["host"] for d in every)),
                 "collective": f"one SUM all-reduce of the flat gradient buffer per step ({self.tr.grad.numel() * 4 / 1e6:.2f} MB fp32)",

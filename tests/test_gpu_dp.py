@@ -144,4 +144,11 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    # the multi-rank line describes what it ran on: backend, world, every rank's device, and the device time
+    # of the one data-path collective per step (HIP events around dp.allreduce_sum_ on every rank)
+    di = d["config"]["distributed"]
+    assert di["backend"] == "gloo" and di["world"] == 2 and di["devices"] == [0, 0] and len(di["device_uuids"]) == 2
+    assert di["allreduces_timed"] == 2 and di["steps_timed"] == 2
+    assert len(di["allreduce_ms_per_step"]) == 2 and all(t > 0 for t in di["allreduce_ms_per_step"])
+    assert "16." in di["collective"] and "all-reduce" in di["collective"]
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d and "secondary" not in d

@@ -264,3 +264,22 @@ def test_hit_ndcg_never_counts_the_invalid_target_signal_as_a_hit():
     hit, ndcg = evaluate.hit_ndcg(torch.tensor([1, 3, 11, -1]))
     assert abs(hit - 2 / 4) < 1e-12
     assert abs(ndcg - (1.0 + 0.5) / 4) < 1e-12
+
+
+def test_bench_refuses_an_rccl_line_with_two_ranks_on_one_device():
+    """the first 8-GPU SCALE run must verify itself — a multi-rank line under backend nccl whose ranks do
+    not each own a device is refused (gloo with both ranks on cuda:0 is the single-GPU test transport and passes)."""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(gio.GOLDEN.rstrip("/")), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = lambda dev, uuid, host="n0": {"rank": dev, "host": host, "device": dev, "uuid": uuid}
+    bench.check_one_device_per_rank("nccl", [r(0, "GPU-a"), r(1, "GPU-b")])
+    bench.check_one_device_per_rank("nccl", [r(0, ""), r(1, "")])                      # no uuid reported: device indices differ
+    bench.check_one_device_per_rank("nccl", [r(0, "GPU-a", "n0"), r(0, "GPU-a", "n1")])  # same index on two hosts
+    bench.check_one_device_per_rank("gloo", [r(0, "GPU-a"), r(0, "GPU-a")])
+    with pytest.raises(SystemExit):
+        bench.check_one_device_per_rank("nccl", [r(0, "GPU-a"), r(0, "GPU-a")])
+    with pytest.raises(SystemExit):
+        bench.check_one_device_per_rank("nccl", [r(0, ""), r(0, "")])
