@@ -99,7 +99,9 @@ def check_one_device_per_rank(backend, ranks):
     """Under backend nccl (RCCL over xGMI) every rank must own its GPU: two ranks that report the same (host, device uuid /
     index) are a mis-launch, and a line measured that way would be mislabelled — refuse it.  (gloo with every rank on cuda:0
     is the single-GPU test transport and passes.)"""
-    keys = [(d["host"], d["uuid"] or d["device"]) for d in ranks]
+    # (the device INDEX a rank has selected, per host: uuids are reported but not trusted — a runtime that answers the same or
+    #  an empty uuid for every GPU must not make a correct launch look like a collision)
+    keys = [(d["host"], d["device"]) for d in ranks]
     if backend == "nccl" and len(set(keys)) != len(ranks):
         raise SystemExit(f"bench.py: backend nccl (RCCL) with two ranks on one device: {ranks}")
 

@@ -277,6 +277,7 @@ def test_bench_refuses_an_rccl_line_with_two_ranks_on_one_device():
     r = lambda dev, uuid, host="n0": {"rank": dev, "host": host, "device": dev, "uuid": uuid}
     bench.check_one_device_per_rank("nccl", [r(0, "GPU-a"), r(1, "GPU-b")])
     bench.check_one_device_per_rank("nccl", [r(0, ""), r(1, "")])                      # no uuid reported: device indices differ
+    bench.check_one_device_per_rank("nccl", [r(0, "00000000"), r(1, "00000000")])      # a runtime with degenerate uuids
     bench.check_one_device_per_rank("nccl", [r(0, "GPU-a", "n0"), r(0, "GPU-a", "n1")])  # same index on two hosts
     bench.check_one_device_per_rank("gloo", [r(0, "GPU-a"), r(0, "GPU-a")])
     with pytest.raises(SystemExit):
