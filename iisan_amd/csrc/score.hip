@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int UB = 32;          // users per workgroup (two 16-user B fragment sets)
-constexpr int MAXH = 64;        // history entries per user handled on the device path
+constexpr int MAXH = 256;       // history entries per user (33 KB of LDS for their raw scores); longer exclusion lists: IISAN_EBADSHAPE
 
 __device__ __forceinline__ bool ahead(float s, int c, float st, int t) { return s > st || (s == st && c < t); }
 

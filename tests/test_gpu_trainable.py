@@ -312,6 +312,66 @@ def test_eval_ranks_match_reference():
     assert abs(float(hit.mean()) - float(z["hit10"])) < 1e-6 and abs(float(ndcg.mean()) - float(z["ndcg10"])) < 1e-6
 
 
+@pytest.mark.parametrize("case", [(1, 17, 0), (33, 500, 3), (97, 2001, 40), (64, 4096, 130), (1000, 20315, 10)])
+def test_score_rank_kernel_shapes_histories_and_ties(case):
+    """The rank kernel of round 3 (32 users per workgroup on the f32 matrix cores, item splits over blockIdx.y, integer
+    atomics; `csrc/score.hip`) against the counting definition of `metrics.py:202-207` evaluated in fp64 on the device, for:
+    user counts that do not fill a workgroup, item counts that do not fill a tile or a split, no history at all, histories
+    longer than a sequence (130 entries), duplicates and zeros inside a history, targets that sit in their own history, invalid
+    targets, and EXACT ties (item rows duplicated: the lower id wins, `oracle.eval_ranks`' rule).  Users whose target score is
+    within 1e-5 of another item's (fp32 summation order could flip those) are excluded from the equality check — there must be
+    few of them."""
+    U, n1, H = case
+    g = torch.Generator().manual_seed(U * 7 + n1 + H)
+    item = torch.randn(n1, 64, generator=g)
+    if n1 > 40:
+        item[7] = item[3]                   # exact ties among items: ids 3 and 7, 11 and 30
+        item[30] = item[11]
+    prec = torch.randn(U, 64, generator=g)
+    tgt = torch.randint(1, n1, (U,), generator=g, dtype=torch.int32)
+    if n1 > 40:
+        tgt[0] = 7                          # a target that ties with a lower id (3 is ahead of it) ...
+        if U > 1:
+            tgt[1] = 11                     # ... and one that ties with a higher id (30 is not)
+    hist = torch.zeros(U, max(H, 1) if H else 0, dtype=torch.int32)
+    if H:
+        hist = torch.randint(0, n1, (U, H), generator=g, dtype=torch.int32)     # zeros and duplicates occur
+        hist[:, 0] = hist[:, -1]                                                  # a guaranteed duplicate
+        if U > 2:
+            hist[2, H // 2] = tgt[2]                                              # target inside its own history
+    if U > 3:
+        tgt[3] = n1 + 5                                                           # invalid target: rank -1
+    ranks = ops.score_rank(prec.cuda(), item.cuda(), hist.cuda(), tgt.cuda()).cpu().long()
+    # definition, fp64
+    sc = prec.double() @ item.double().t()
+    n_close = 0
+    for u in range(U):
+        t = int(tgt[u])
+        if t <= 0 or t >= n1:
+            assert ranks[u] == -1
+            continue
+        s = sc[u].clone()
+        hs = [int(h) for h in hist[u].tolist() if 0 < int(h) < n1] if H else []
+        if hs:
+            s[torch.tensor(hs)] = -float("inf")
+        st = s[t]
+        ids = torch.arange(n1)
+        ahead = (s > st) | ((s == st) & (ids < t))
+        ahead[0] = False
+        ref = 1 + int(ahead.sum())
+        raw = sc[u].clone()
+        raw[t] = float("inf")
+        exact_tie = {3: 7, 7: 3, 11: 30, 30: 11}.get(t, -1)
+        if exact_tie >= 0:
+            raw[exact_tie] = float("inf")                       # a bit-exact tie is decided by the id, not by rounding
+        close = st != -float("inf") and float((raw - sc[u][t]).abs().min()) < 1e-5
+        if close:
+            n_close += 1
+            continue
+        assert int(ranks[u]) == ref, (u, t, int(ranks[u]), ref)
+    assert n_close <= max(2, U // 20)
+
+
 def _drop_factors(seed, site, n, p):
     """numpy re-implementation of drop_scale() in iisan_amd/csrc/common.h."""
     M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
