@@ -306,6 +306,20 @@ int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStr
         }
         else rest[nr++] = pr[i];
     }
+    // A skinny long-K product (Versa's fc_bert: [1408, 8192] -> 64) must not share a launch with short-K ones: alone it takes the
+    // split-K route through the executor's scratch (33 us); grouped, the launch has "enough" workgroups, nothing is split and its
+    // 22 workgroups walk 128 K-tiles each while the rest of the chip idles (195 us per Versa step, profiles/r3a_versa_*).
+    if (nr > 1 && !(flags & G32_ACCUM)) {
+        int64_t kmin = INT64_MAX;
+        for (int i = 0; i < nr; ++i) kmin = rest[i].K < kmin ? rest[i].K : kmin;
+        for (int i = 0; i < nr;) {
+            if (rest[i].N <= 64 && rest[i].K >= 4096 && rest[i].K >= 4 * kmin) {
+                IISAN_TRY(launch_gemm32(&rest[i], 1, flags & ~G32_HINT_B_EXACT16, s));
+                for (int k = i; k + 1 < nr; ++k) rest[k] = rest[k + 1];
+                --nr;
+            } else ++i;
+        }
+    }
     if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags & ~G32_HINT_B_EXACT16, s));
     return IISAN_OK;
 }
