@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Finer slot timeline of gemm16_h256 (development aid of round 3): like tools/gemm_slots_h.py, with extra stamps inside the
+last step's [Rhi + E] slot (after the arithmetic, after the stores, after lgkmcnt, after vmcnt).  Needs tools/lib_timeline.so built with
+-DS256_TIMELINE -DS256_FINE and the `stamp2()` calls of that experiment in the kernel (they are not in the tree any more; kept for
+the record of how DESIGN 6e's per-stage cycle counts were taken).  python tools/slots_fine.py [debug bits ...]"""
 import sys, os
 import torch
 sys.path.insert(0, "/root/repo")
