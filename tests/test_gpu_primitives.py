@@ -63,6 +63,31 @@ def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
     assert err <= tol, f"gemm16 variant={variant} dt={dt} mode={mode} {shape}: max err {err:.3e} > {tol:.3e}"
 
 
+@pytest.mark.parametrize("shape", [(70000, 2304, 768, 0), (42240, 3072, 768, 1), (66000, 768, 3072, 0), (1300, 768, 256, 0)])
+def test_gemm16_h256_race_screen_against_the_s256_kernel(lib, shape):
+    """Race screen of the half-slot tile boundary (`csrc/gemm16_h256.hip`): its LDS-DMA pieces are issued from other slots than
+    in `gemm16_s256.hip`, and a piece read before it has landed gives rare wrong tiles that come and go with memory load
+    (cdna_hip_programming.md: place reads by the vmcnt / barrier count, never by clean runs).  Both kernels are deterministic
+    and accumulate in the same order, so every run of either must give the same bits: 20 runs on fresh operands each, many
+    tiles per workgroup (70,000 rows x 9 column tiles = 2,466 tiles on 256 CUs), a ragged last row tile, K = 768 and 3072,
+    the minimum K the kernel takes (four K-steps), plain and GELU epilogues."""
+    M, N, K, mode = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    out = {v: torch.empty(M, N, dtype=torch.float16, device="cuda") for v in (3, 4)}
+    for it in range(20):
+        A = _pad_rows((torch.randn(M, K, generator=g, device="cuda") * 0.5).half())
+        W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+        bias = torch.randn(N, generator=g, device="cuda") * 0.3
+        for v in (3, 4):
+            lib.iisan_set_gemm16_variant(v)
+            out[v].fill_(float("nan"))
+            _lib.check(lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out[v].data_ptr(), None, M, N, K, _stream()), "gemm16")
+        lib.iisan_set_gemm16_variant(0)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out[4]).all(), f"iteration {it}: rows not written"
+        assert torch.equal(out[3], out[4]), f"iteration {it}: {(out[3].float() - out[4].float()).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 def test_layernorm768_vs_torch(lib, dt):
     g = torch.Generator().manual_seed(3)
