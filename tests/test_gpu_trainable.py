@@ -941,6 +941,55 @@ def test_out_of_range_ids_are_loud_not_wild_reads():
     assert hit == pytest.approx(1 / 3) and ndcg == pytest.approx(1 / 3)
 
 
+def test_backward_follows_the_route_its_forward_took_not_the_knobs_of_the_moment(lib):
+    """backward routes used to be chosen from process-global knobs.  (1) `iisan_inbatch_ce_bwd` after a forward on the
+    fused fast path only scales the d_prec the forward left in the workspace — with the knob flipped in between it must still do
+    that (and after a forward on the slow path it must NOT read that uninitialised area): gradients equal the unflipped run's.
+    (2) `iisan_side_net_bwd` marks amax slots "ready" that only a forward with the same split-operand routing has filled: a
+    changed routing between the two calls is an error, not silent garbage."""
+    bs, S, E, n = 64, 10, 64, 300
+    b = synth.scientific_batch(bs=bs, seed=5, item_num=n, res=2, words=2)
+    g = torch.Generator().manual_seed(2)
+    ids, lm, pop = b.ids.view(-1).cuda(), b.log_mask.cuda(), b.pop_prob.cuda()
+
+    def ce(flip_from, flip_to):
+        score = torch.randn(bs * (S + 1), E, generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
+        prec = torch.randn(bs * S, E, generator=torch.Generator().manual_seed(8)).cuda().requires_grad_(True)
+        lib.iisan_set_ce_fast(flip_from)
+        try:
+            loss = ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
+            lib.iisan_set_ce_fast(flip_to)
+            loss.backward()
+        finally:
+            lib.iisan_set_ce_fast(1)
+        return loss.detach().clone(), score.grad.clone(), prec.grad.clone()
+
+    base = ce(1, 1)
+    for a, bb in ((1, 2), (2, 1), (1, 0), (0, 1)):
+        got = ce(a, bb)
+        for x, y, what in zip(got, base, ("loss", "d_score", "d_prec")):
+            assert torch.isfinite(x).all(), (a, bb, what)
+            scale = y.abs().max().item() + 1e-20
+            assert (x - y).abs().max().item() <= 2e-5 * scale, (a, bb, what, (x - y).abs().max().item(), scale)
+
+    # (2) side network: x3 routing changed between forward and backward -> IisanHipError
+    z, bb_, taps_cv, taps_tx, P, kw = gio.sidenet_full_inputs("default")
+    args = helpers.make_args()
+    model = helpers.build_model(args, 50, bb_.pop_prob, cached=True)
+    helpers.load_trainables(model, P)
+    bsz, S_ = bb_.log_mask.shape
+    tc = taps_cv.view(bsz, S_ + 1, 13, 768).cuda()
+    tt = taps_tx.view(bsz, S_ + 1, 13, 768).cuda()
+    lib.iisan_set_x3(1)
+    try:
+        cv, (text, mm) = model.mm_encoder(tc, tt)
+        lib.iisan_set_x3(2)
+        with pytest.raises(_lib.IisanHipError, match="routing"):
+            (cv.sum() + text.sum() + mm.sum()).backward()
+    finally:
+        lib.iisan_set_x3(1)
+
+
 def test_cached_step_on_a_poisoned_heap_is_finite_and_its_weight_gradients_reproducible(lib):
     """The executor's workspace comes from torch's caching allocator uninitialised.  Regression: a split-K partial that no
     workgroup wrote (an empty K range) was summed by the reducer — NaN gradients that depended on what the heap held before.
