@@ -551,8 +551,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
                                   size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     Ctx c;
-    IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_bwd"));
-    {   // the amax slots this call marks "ready" were filled by the forward call only on the routes IT took
+    {   // (before setup(): a changed routing also changes the workspace layout.)  The amax slots this call marks "ready" were filled by the forward call only on the routes IT took
         uint64_t fwd_route = 0;
         if (!iisan_route_find(ws, ROUTE_SIDE_X3, &fwd_route)) {
             iisan_set_error("side_net_bwd: no side_net_fwd call has filled this workspace");
@@ -563,6 +562,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
             return IISAN_EBADSHAPE;
         }
     }
+    IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_bwd"));
     const Plan& p = c.p;
     SideBufs& b = c.b;
     ScratchGuard guard(b.skws, b.skws_floats);
