@@ -87,6 +87,8 @@ SIGNATURES = {
 EXTRA_SIGNATURES = {
     "iisan_timing_enable": (None, [i32]),
     "iisan_set_gemm16_variant": (None, [i32]),
+    "iisan_set_gemm16_walk": (None, [i32, i32]),
+    "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_gemm16_h256": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),

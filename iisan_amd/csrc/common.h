@@ -250,6 +250,7 @@ struct Gemm16Args {
     int32_t qkv_S, qkv_heads;   // EPI_QKVH16: tokens per item and heads of the head-major QKV layout
     int32_t qkv_which0;         // EPI_QKVH16: first of q|k|v (0..2) the N = (3 - which0)*64*heads columns hold (1 = K and V only)
     int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
+    int32_t walk_c, walk_h;     // gemm16_h256 tile walk: panels of walk_c column tiles, sub-slabs of walk_h row tiles per XCD (0 = row-major list)
     // EPI_F32 (split-operand GEMM of the trainable path, split.hip): out fp32 = acc * inv_a[0] * inv_b[0] (+ bias) (+ resid)
     const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
     int32_t atomic;     // 1: accumulate into out with fp32 atomics (bench knob only: ~20 G atomics/s chip-wide, far too slow)

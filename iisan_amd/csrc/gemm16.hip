@@ -264,6 +264,10 @@ extern "C" void iisan_set_gemm16_h256(int32_t on) { g_auto_h256 = on; }
 static int g_desync = 0;
 extern "C" void iisan_set_gemm16_desync(int32_t on) { g_desync = on; }
 extern "C" void iisan_set_gemm16_variant(int v) { g_variant = v; }
+// tile walk of gemm16_h256 (bench knob): c = -1 auto policy, 0 = row-major tile list, > 0 = panels of c column tiles walked down
+// sub-slabs of h row tiles (h <= 0: the XCD's whole slab)
+static int g_walk_c = -1, g_walk_h = 0;
+extern "C" void iisan_set_gemm16_walk(int32_t c, int32_t h) { g_walk_c = c; g_walk_h = h; }
 
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0, "gemm16: empty problem M=%lld N=%d K=%d", (long long)a.M, a.N, a.K);
@@ -281,6 +285,12 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     if (big && (var == 4 || (var == 0 && g_auto_staggered && g_auto_h256)) && gemm16_h256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
+        // auto policy (tools/gemm_walk.py, three boxes, interleaved rounds: QKV 1,010 -> 1,045, FC1 972 -> 990 TFLOP/s; the L2 read
+        // latency seen by the L1 falls from 396 to 239 cycles, profiles/r4_gemm_l2.md): panels of 3 column tiles walked down
+        // sub-slabs of 16 row tiles wherever a tile row is at least two panels wide and every XCD's slab holds a few sub-slabs
+        const bool auto_panel = a.N / 256 >= 6 && ceil_div(a.M, 256) >= 128;
+        b.walk_c = g_walk_c < 0 ? (auto_panel ? 3 : 0) : g_walk_c;
+        b.walk_h = g_walk_c < 0 ? 16 : g_walk_h;
         rc = launch_gemm16_h256(dtype16, mode, b, s);
         if (timed) iisan_timing_post(s);
         return rc;
@@ -308,5 +318,16 @@ extern "C" int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const 
     Gemm16Args a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = nullptr;
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = 0;
+    return launch_gemm16(dtype16, mode, a, (hipStream_t)stream);
+}
+
+// bench entry (not in the product ABI): the same product with explicit leading dimensions (elements) — tools/gemm_ld.py
+// asks whether the row stride of the operands (1536 B at K = 768) costs L2 channel parallelism.
+extern "C" int iisan_gemm16_ld(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,
+                               int64_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, void* stream) {
+    IISAN_CHECK_SHAPE(mode >= 0 && mode <= 1, "iisan_gemm16_ld: mode must be 0 or 1");
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo;
     return launch_gemm16(dtype16, mode, a, (hipStream_t)stream);
 }

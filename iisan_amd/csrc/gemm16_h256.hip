@@ -95,12 +95,54 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     const int wq = wave & 3;              // wave within the group = its 64-column slice of the tile
 
     const int G = gridDim.x;
-    const int pid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int ntiles = tiles_m * tiles_n;
-    const int my_tiles = pid < ntiles ? (ntiles - pid + G - 1) / G : 0;
     const int nk = p.K / SBK;
+    // ---- tile walk ----
+    // The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only: any placement computes the same tiles).
+    // Legacy walk (walk_c == 0): XCD x takes 32 consecutive tiles of the row-major tile list per round — at 9..12 column tiles
+    // that is 2.7..3.6 row tiles x EVERY column tile: the whole W (3.5 / 4.7 MB for QKV / FC1) passes through the XCD's 4-MB
+    // L2 every round.  Panel walk (walk_c = C > 0): XCD x owns the row tiles [x tiles_m / 8, (x+1) tiles_m / 8) and walks them
+    // in sub-slabs of walk_h row tiles; inside a sub-slab it goes panel by panel (C column tiles wide), row-major inside a
+    // panel, 32 consecutive positions per round: a round is ~32/C row tiles x C column tiles, the W panel (C x 393 KB at
+    // K = 768) is the same for walk_h * C / 32 rounds, and the A rows of a sub-slab come back once per panel.
+    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3, L = G >> 3;
+    // walk_c == 0: one slab of every row tile, one panel of every column tile, position pid + ti * G — the row-major list
+    const bool panel = p.walk_c > 0;
+    const int wC = panel ? p.walk_c : tiles_n, wH = panel ? p.walk_h : tiles_m;
+    const int slab0 = panel ? (int)(((int64_t)xcd * tiles_m) >> 3) : 0;
+    const int slab_rows = panel ? (int)(((int64_t)(xcd + 1) * tiles_m) >> 3) - slab0 : tiles_m;
+    const int pid = xcd * L + lidx;
+    const int ntiles = slab_rows * tiles_n;
+    const int first = panel ? lidx : pid, stride = panel ? L : G;
+    const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
     const int nsteps = my_tiles * nk;
     if (nsteps == 0) return;
+    // coordinates of this workgroup's ti-th tile (wave-uniform; computed once per tile, in a read slot)
+    auto walk = [&](int ti, int& tm, int& tn) {
+        const int n = first + ti * stride;
+        const int HT = wH * tiles_n;
+        const int sb = n / HT, rem = n - sb * HT;
+        const int left = slab_rows - sb * wH;
+        const int hrows = left < wH ? left : wH;
+        const int PT = hrows * wC;
+        const int pn = rem / PT, rem2 = rem - pn * PT;
+        const int cleft = tiles_n - pn * wC;
+        const int cw = cleft < wC ? cleft : wC;
+        const int row = rem2 / cw;
+        tm = __builtin_amdgcn_readfirstlane(slab0 + sb * wH + row);
+        tn = __builtin_amdgcn_readfirstlane(pn * wC + (rem2 - row * cw));
+    };
+    int cur_tm, cur_tn, nxt_tm, nxt_tn, prev_tm = 0, prev_tn = 0;
+    walk(0, cur_tm, cur_tn);
+    nxt_tm = cur_tm; nxt_tn = cur_tn;
+    if (my_tiles > 1) walk(1, nxt_tm, nxt_tn);
+    // tile and K-step of flat step (current tile, kt + d), d = 1, 2 (nk >= 2: never beyond the next tile).  After the last tile
+    // `nxt` repeats `cur`: past the end of the workgroup's steps the plan re-loads steps 0 / 1 of the last tile into buffers
+    // nobody reads any more (any valid address will do).
+    auto step_at = [&](int kt, int d, int& tm, int& tn, int& k) {
+        k = kt + d;
+        tm = cur_tm; tn = cur_tn;
+        if (k >= nk) { tm = nxt_tm; tn = nxt_tn; k -= nk; }
+    };
 
     // staging offsets, kept to 5 VGPRs: lane -> row-in-chunk r8 = lane>>3, physical slot lane&7; the logical slot is
     // physical ^ ((row>>1)&7) = s0 ^ 4*(j&1) for chunk j of a 32-row-aligned run, s0 = (lane&7) ^ (lane>>4).
@@ -114,18 +156,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 
     // One 1-KiB piece (8 LDS rows) of the A-operand half `h` / the W half `h` of flat step s; wave wq owns rows
     // h*128 + wq*32 .. +31 of a half, piece j = rows +8j.
-    auto piece_A = [&](int s, int h, int j) {
-        const int ti = s / nk, kt = s - ti * nk;
-        const int tau = pid + ti * G;
-        const int tm = tau / tiles_n;
+    auto piece_A = [&](int s, int h, int j) {      // prologue only: s = 0, 1 lie in the first tile (nk >= 2)
+        const int kt = s, tm = cur_tm;
         const int q0 = h * 128 + wq * 32;
         const char* Ag = Abase + (((int64_t)tm * SBM + q0 + 8 * j) * p.lda + (int64_t)kt * SBK) * 2 + rowA;
         glds16(Ag + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + (q0 + 8 * j) * 128);
     };
     auto piece_W = [&](int s, int h, int j) {   // LDS rows q0+8j.. hold W rows q0 + 4j + {0,16} + {0..3} (nperm32s)
-        const int ti = s / nk, kt = s - ti * nk;
-        const int tau = pid + ti * G;
-        const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
+        const int kt = s, tn = cur_tn;
         const int q0 = h * 128 + wq * 32;
         const char* Wg = Wbase + (((int64_t)tn * SBN + q0 + 4 * j) * p.ldw + (int64_t)kt * SBK) * 2 + rowW;
         glds16(Wg + ((j & 1) ? slotx1 : slotx0), smem + (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (q0 + 8 * j) * 128);
@@ -202,24 +240,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     // Group A: pieces 0..3 = B's A-operand half of step s+1, 4..7 = A's own half of step s+2;
     // group B: the W tile of step s+2 (pieces 0..3 rows 0..127, 4..7 rows 128..255).
-    auto make_plan = [&](int s) {
+    auto make_plan = [&](int s, int kt) {          // kt = K-step of flat step s inside the current tile (-1: before step 0)
         Plan q;
-        const int last = nsteps - 1;
         uint64_t g1, g2;
+        int tm2, tn2, kt2;
+        step_at(kt, 2, tm2, tn2, kt2);
         if (grp == 0) {
-            const int s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last;
-            const int ti1 = s1 / nk, kt1 = s1 - ti1 * nk, tm1 = (pid + ti1 * G) / tiles_n;
-            const int ti2 = s2 / nk, kt2 = s2 - ti2 * nk, tm2 = (pid + ti2 * G) / tiles_n;
+            int tm1, tn1, kt1;
+            step_at(kt, 1, tm1, tn1, kt1);
             g1 = (uint64_t)Abase + (((int64_t)tm1 * SBM + 128 + wq * 32) * p.lda + (int64_t)kt1 * SBK) * 2;
             g2 = (uint64_t)Abase + (((int64_t)tm2 * SBM + wq * 32) * p.lda + (int64_t)kt2 * SBK) * 2;
             q.l1 = ((s + 1) & 1) * S_STAGE_BYTES + (128 + wq * 32) * 128;
             q.l2 = (s & 1) * S_STAGE_BYTES + (wq * 32) * 128;
         } else {
-            const int s2 = s + 2 < last ? s + 2 : last;
-            const int ti = s2 / nk, kt = s2 - ti * nk;
-            const int tau = pid + ti * G;
-            const int tm = tau / tiles_n, tn = tau - tm * tiles_n;
-            g1 = (uint64_t)Wbase + (((int64_t)tn * SBN + wq * 32) * p.ldw + (int64_t)kt * SBK) * 2;
+            g1 = (uint64_t)Wbase + (((int64_t)tn2 * SBN + wq * 32) * p.ldw + (int64_t)kt2 * SBK) * 2;
             g2 = g1 + (uint64_t)128 * p.ldw * 2;
             q.l1 = (s & 1) * S_STAGE_BYTES + S_OP_BYTES + (wq * 32) * 128;
             q.l2 = q.l1 + 128 * 128;
@@ -402,8 +436,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
                     }
                     if (ok) {
-                        *(V8*)op = o0;
-                        *(V8*)(op + 16) = o1;
+                        if (p.debug & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
+                            __builtin_nontemporal_store(o0, (V8*)op);
+                            __builtin_nontemporal_store(o1, (V8*)(op + 16));
+                        } else {
+                            *(V8*)op = o0;
+                            *(V8*)(op + 16) = o1;
+                        }
                     }
                 }
             };
@@ -474,16 +513,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // half-epilogue of this slot issued exactly 8 store instructions (full row tile, stores enabled), all YOUNGER than the
     // loads the wait is for: `vmcnt(8)` lets them fly on.
     using std::integral_constant;
-    Plan qprev = make_plan(-1);        // pieces 4..7: what the prologue loaded for step 1 (re-issued identically at s = 0)
-    // tile coordinates of the tile being computed and of the one before it, carried incrementally (tile index += G per tile)
-    const int dG_m = G / tiles_n, dG_n = G - dG_m * tiles_n;
-    int cur_tm = pid / tiles_n, cur_tn = pid - cur_tm * tiles_n, prev_tm = 0, prev_tn = 0;
+    Plan qprev = make_plan(-1, -1);    // pieces 4..7: what the prologue loaded for step 1 (re-issued identically at s = 0)
+    int ti = 0;                        // index of the tile being computed in this workgroup's walk
     if (grp == 1) S256_BARRIER();      // B: slot 0 (A is in Rlo(0))
     for (int s = 0; s < nsteps;) {
         {
             // ======== first K-step of a tile: Rlo | Mlo | Rhi + E(hi, previous tile) | Mhi ========
             read_lo(s);
-            const Plan q = make_plan(s);
+            const Plan q = make_plan(s, 0);
             S256_LGKM0();
             S256_FENCE();              // nothing to wait for: the only vector-memory operations in flight are stores
             stamp();
@@ -509,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         for (int kt = 1; kt < nk - 1; ++kt, ++s) {
             // ======== middle K-steps: R | M (as gemm16_s256.hip) ========
             read_step(s);
-            const Plan q = make_plan(s);
+            const Plan q = make_plan(s, kt);
             S256_LGKM0();
             S256_VMCNT(0);             // the pieces of the previous MFMA slot (after a first step: the hi half's stores too, two slots old)
             stamp();
@@ -522,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         {
             // ======== last K-step of a tile: Rlo | Mlo | Rhi + E(lo) | Mhi ========
             read_lo(s);
-            const Plan q = make_plan(s);
+            const Plan q = make_plan(s, nk - 1);
             S256_LGKM0();
             S256_VMCNT(0);
             stamp();
@@ -545,8 +582,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             qprev = q;
             ++s;
             prev_tm = cur_tm; prev_tn = cur_tn;
-            cur_tm += dG_m; cur_tn += dG_n;
-            if (cur_tn >= tiles_n) { cur_tn -= tiles_n; ++cur_tm; }
+            cur_tm = nxt_tm; cur_tn = nxt_tn;
+            ++ti;
+            if (ti + 1 < my_tiles) walk(ti + 1, nxt_tm, nxt_tn);
         }
     }
     epilogue(prev_tm, prev_tn, 1);     // the last tile's hi rows
@@ -578,7 +616,11 @@ int launch_epi(const Gemm16Args& a, hipStream_t s) {
     grid = (grid + 7) / 8 * 8;
     // EPI_QKVH16: item = row / S as one v_mul_hi_u32 by floor(2^32 / S) + 1 — exact while row * S < 2^32 (gemm16_h256_applicable)
     const uint32_t magic = a.qkv_S > 0 ? (uint32_t)((1ull << 32) / (uint64_t)a.qkv_S) + 1u : 0u;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a, tiles_m, tiles_n, magic);
+    Gemm16Args b = a;
+    // the panel walk needs at least one row tile per XCD slab and a panel narrower than the tile row
+    if (b.walk_c >= tiles_n || tiles_m < 8 || b.walk_c < 0) b.walk_c = 0;
+    if (b.walk_c > 0 && (b.walk_h <= 0 || b.walk_h > tiles_m)) b.walk_h = tiles_m;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, b, tiles_m, tiles_n, magic);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
