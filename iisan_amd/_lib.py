@@ -92,6 +92,7 @@ EXTRA_SIGNATURES = {
     "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_gemm16_h256": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),
+    "iisan_set_resid32": (None, [i32]),
     "iisan_set_x3": (None, [i32]),
     "iisan_set_sanb_fused": (None, [i32]),
     "iisan_set_sanb_debug": (None, [i32]),

@@ -269,6 +269,11 @@ int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, co
 // ... with a second 16-bit delta: v = (x + delta16) + delta16b (either may be null)
 int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, const void* delta16b, const float* g,
                              const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
+// mixed-precision residual stream (rowops.hip: layernorm768_mixed_kernel): CLS rows fp32 in `xc` [items, 768], every other token
+// row fp16 in `x16` [items * Ttok, 768]; V = which operands exist
+enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64 };
+int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
+                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)

