@@ -55,9 +55,11 @@ def parse(argv=None):
     ap.add_argument("--dedup", action="store_true",
                     help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
                          "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
-    ap.add_argument("--overlap-towers", action="store_true",
-                    help="opt-in: BERT tower on a second HIP stream beside the ViT tower (same results, about -2 %% step time; the "
-                         "per-launch GEMM durations then overlap other kernels, so roofline.achieved stops being a kernel measure)")
+    ap.add_argument("--overlap-towers", dest="overlap_towers", action="store_true", default=True,
+                    help="(the product default since round 4) BERT tower on a second HIP stream beside the ViT tower: same results, "
+                         "-2.4 %% step time; `roofline` then times the launches on the main stream, i.e. the ViT tower's GEMMs")
+    ap.add_argument("--no-overlap-towers", dest="overlap_towers", action="store_false",
+                    help="both towers on one stream (rounds 1-3): every gemm16 launch is timed")
     ap.add_argument("--cached", choices=["fp32", "fp16", "bf16"], default=None,
                     help="secondary workload (BASELINE config 3, never the headline): Code_Cached IISAN fed from a "
                          "device-resident packed tap store of the given precision; use with --bs 1024")
@@ -316,7 +318,7 @@ def pmc_traffic(a):
     """Measured memory-side bytes per gemm16 launch of the DEFAULT configuration, from the committed summary of the two PMC
     passes (tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run, so any other configuration
     reports null."""
-    default = (a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup and not a.overlap_towers
+    default = (a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup and a.overlap_towers
                and not a.cached and a.chunk == 0)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not default or not os.path.exists(path):
@@ -419,6 +421,8 @@ class Uncached:
         if overlap is not None:
             enc.overlap_towers = overlap
         clock = Clock(self.dev, world)
+        # overlapped towers: only the launches on the main stream (the ViT tower) are a kernel measure (csrc/timing.cpp)
+        lib.iisan_timing_only_stream(torch.cuda.current_stream().cuda_stream, 1 if enc.overlap_towers else 0)
         try:
             if world > 1:                       # warm-up outside the all-reduce timing, then HIP events around every collective
                 for _ in range(warmup):
@@ -431,6 +435,8 @@ class Uncached:
                 elapsed, loss = clock.run(self.step, warmup, steps, lib, timed=self.rank == 0)
         finally:
             lib.iisan_set_full_blocks(0)
+            lib.iisan_timing_only_stream(None, 0)
+            overlapped = enc.overlap_towers
             enc.overlap_towers = prev_overlap
             self.tr.time_allreduce = False
         dinfo = self.dist_info(steps) if world > 1 else None
@@ -450,8 +456,9 @@ class Uncached:
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        **({"distributed": dinfo} if dinfo else {}),
-                       **({"towers": "BERT on a second HIP stream beside ViT (opt-in; per-launch GEMM durations overlap other kernels)"}
-                          if (a.overlap_towers if overlap is None else overlap) else {}),
+                       "towers": ("text tower on a second HIP stream beside the image tower (same kernels, same results); `roofline` times the "
+                                  "gemm16 launches of the main stream = the ViT tower (87 % of the encoder GEMM FLOPs)") if overlapped
+                                 else "both towers on one stream; `roofline` times every gemm16 launch",
                        "encoder_blocks": "all tokens in every block" if full_blocks else
                                          "WORK PRUNING: last block computes K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
@@ -460,7 +467,8 @@ class Uncached:
                          # this command with this configuration, profiles/pmc_traffic.json; null for any other configuration)
                          "traffic": pmc_traffic(a) if (headline and dtype == a.dtype and full_blocks == a.full_blocks) else None,
                          "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1),
-                         "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders; flops = executed, by launch)",
+                         "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders"
+                                   + (", ViT tower = the launches on the main stream" if overlapped else "") + "; flops = executed, by launch)",
                          "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                          "flop_per_launch": fl.value / max(n_launch, 1),
                          # whole step: GEMM FLOPs actually executed in the timed region / wall time / peak (dead work the
@@ -573,8 +581,8 @@ def secondary_lines(a, unc, lib, dev, rank, world):
         "on the CLS rows only (taps identical)", lambda: unc.line(k, w, "fp16", False, headline=False))
     add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", True, headline=False))
     unc.set_dtype(a.dtype)
-    add("uncached, text tower on a second HIP stream beside the image tower (same results; its per-launch GEMM durations overlap "
-        "other kernels, so `roofline` is not a kernel measure here)", lambda: unc.line(k, w, a.dtype, True, headline=False, overlap=True))
+    add("uncached, both towers on ONE stream (rounds 1-3; every gemm16 launch of the step is timed)",
+        lambda: unc.line(k, w, a.dtype, True, headline=False, overlap=False))
     unc.set_dtype(a.dtype)
     c3 = argparse.Namespace(**{**vars(a), "cached": "fp32", "versa": False, "bs": 1024})
     add("BASELINE config 3: Code_Cached IISAN bs=1024, fp32 tap store", lambda: cached_line(c3, lib, dev, rank, world, 10, 3))
@@ -632,7 +640,7 @@ def main():
         if check:
             out["config"]["kernel_family_check"] = check
         default = (world == 1 and a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup
-                   and not a.overlap_towers and a.chunk == 0)
+                   and a.overlap_towers and a.chunk == 0)
         if default and not a.no_secondary:
             out["secondary"] = secondary_lines(a, unc, lib, dev, rank, world)
         if world == 1 and not a.no_cpu_baseline:

@@ -86,6 +86,7 @@ SIGNATURES = {
 # bench-only helpers (not declared in include/iisan_hip.h)
 EXTRA_SIGNATURES = {
     "iisan_timing_enable": (None, [i32]),
+    "iisan_timing_only_stream": (None, [vp, i32]),
     "iisan_set_gemm16_variant": (None, [i32]),
     "iisan_set_gemm16_walk": (None, [i32, i32]),
     "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
@@ -97,6 +98,8 @@ EXTRA_SIGNATURES = {
     "iisan_set_sanb_fused": (None, [i32]),
     "iisan_set_sanb_debug": (None, [i32]),
     "iisan_set_sanb_schedule": (None, [i32, i32]),
+    "iisan_set_sasrec_fused": (None, [i32]),
+    "iisan_set_sasrec_stamps": (None, [vp]),
     "iisan_set_ce_debug": (None, [i32]),
     "iisan_set_ce_fast": (None, [i32]),
     "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),

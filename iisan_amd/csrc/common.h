@@ -230,7 +230,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // per-launch HIP-event timing of the dominant kernel (timing.cpp); used by bench.py only
-bool iisan_timing_on();          // class 1 (gemm16) enabled
+bool iisan_timing_on(hipStream_t s);   // class 1 (gemm16) enabled for launches on stream s
 int iisan_timing_class();       // 0 = off, 1 = gemm16, 2 = the gemm32.hip family
 void iisan_timing_pre(hipStream_t s, double flops, double bytes);
 void iisan_timing_post(hipStream_t s);

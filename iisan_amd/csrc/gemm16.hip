@@ -277,7 +277,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
     IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.qkv_which0 >= 0 && a.qkv_which0 <= 2 && a.N == (3 - a.qkv_which0) * 64 * a.qkv_heads),
                       "gemm16: head-major QKV mode needs S, heads and N == 3*64*heads");
-    const bool timed = iisan_timing_on();
+    const bool timed = iisan_timing_on(s);
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N));
     const int var = g_variant & 0xff;
     const bool big = var == 2 || var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);

@@ -18,6 +18,15 @@
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
                   int nprob, hipStream_t s);
 
+// one-launch forward / backward for the production shape (sasrec_fused.hip); works on the workspace slots carved here
+struct SasFusedPtrs {
+    float* Z0; float* X0;
+    float* Q[8]; float* K[8]; float* V[8]; float* P[8]; float* C[8]; float* Zattn[8]; float* X1[8]; float* Hf[8]; float* Zffn[8]; float* X2[8];
+};
+bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg);
+int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B, const void* const* params,
+                            float* y, const SasFusedPtrs& w, hipStream_t s);
+
 namespace {
 
 constexpr int MAXE = 256;   // d_model up to 256 (multiple of 64)
@@ -284,6 +293,17 @@ Gemm32Prob prob(const float* A, int lda, const float* B, int ldb, const float* b
     return p;
 }
 
+SasFusedPtrs fused_ptrs(const SasBufs& b, int blocks) {
+    SasFusedPtrs w{};
+    w.Z0 = b.Z0; w.X0 = b.X0;
+    for (int l = 0; l < blocks; ++l) {
+        const BlockBufs& k = b.blk[l];
+        w.Q[l] = k.Q; w.K[l] = k.K; w.V[l] = k.V; w.P[l] = k.P; w.C[l] = k.C; w.Zattn[l] = k.Zattn; w.X1[l] = k.X1;
+        w.Hf[l] = k.Hf; w.Zffn[l] = k.Zffn; w.X2[l] = k.X2;
+    }
+    return w;
+}
+
 // parameter table: 0 pos, 1 ln.w, 2 ln.b, then 12 per block:
 // +0 wQ +1 wK +2 wV +3 fc +4 attn_ln.w +5 attn_ln.b +6 w1.w +7 w1.b +8 w2.w +9 w2.b +10 ffn_ln.w +11 ffn_ln.b
 inline int pb(int l, int i) { return 3 + 12 * l + i; }
@@ -308,6 +328,7 @@ extern "C" int iisan_sasrec_fwd(const iisan_sasrec_cfg* cfg, const float* x, con
         iisan_set_error("sasrec_fwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
     }
+    if (sasrec_fused_ok(cfg)) return launch_sasrec_fused_fwd(cfg, x, log_mask, B, params, y, fused_ptrs(b, cfg->blocks), s);
     const int S = cfg->seq, E = cfg->emb, H = cfg->heads, dh = E / H;
     const int64_t T = B * S;
     auto W = [&](int i) { return (const float*)params[i]; };

@@ -1,0 +1,322 @@
+// SASRec user encoder, ONE launch per direction (round 4).
+// Replaces, for the production shape (d_model 64, sequences of <= 16 positions), the 15-launch forward and the ~34-launch backward
+// of sasrec.hip — User_Encoder.forward (Code_Uncached/model/encoders.py:60-65) -> TransformerEncoder / TransformerBlock /
+// MultiHeadedAttention / SelfAttention / PositionwiseFeedForward (Code_*/model/modules.py:6-96).  The whole encoder is ~2 MFLOP per
+// sequence: as separate launches it cost 0.8 ms per step at ANY batch size (45 kernels of 5-25 us each: launch ramps and
+// dependent-kernel boundaries), i.e. more than the in-batch CE of the Cached step.
+//
+// One 256-thread workgroup owns G = 48 / S consecutive sequences (R = G S <= 48 rows of 64 floats) from the position embedding to the
+// last LayerNorm; the rows never leave LDS between operators.  Every product is [R, 64] x [64, 64]^T on `v_mfma_f32_16x16x4_f32`
+// (exact fp32): wave w owns output columns 16 w ..+15 of all row tiles; the weight fragment comes straight from L2 (one 16-byte load
+// per lane and 16 contraction steps — the contraction index of MFMA (t, e) is 16 t + 4 g + e, so both operands are 16-byte reads),
+// the activation fragment is one conflict-free ds_read_b128 from a [48][68] LDS image.  The 64 -> 256 -> 64 FFN runs in four chunks
+// of 64 hidden units whose second product accumulates in registers.  Attention (S x S per sequence and head), softmax, LayerNorm and
+// the counter-based dropout (common.h: same sites and element indices as sasrec.hip) are plain per-thread / per-wave code on the LDS
+// rows.  Every intermediate the backward needs is written to the same workspace slots sasrec.hip uses (coalesced 16-byte stores of
+// whole LDS tiles), so either backward can follow either forward.
+#include "common.h"
+
+namespace {
+
+constexpr int FE = 64;            // d_model
+constexpr int FR = 48;            // rows per workgroup (3 MFMA row tiles): 4 sequences of 10 positions — one workgroup per CU at bs = 1024
+constexpr int FLD = 68;           // LDS row stride (floats): 16 rows x 16 bytes of a ds_read_b128 lane group cover all 64 banks
+constexpr int FNT = FR / 16;
+
+struct FusedBlk {                  // per block: parameters and workspace slots (sasrec.hip: BlockBufs)
+    const float *wq, *wk, *wv, *wfc, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+    float *Q, *K, *V, *P, *C, *Zattn, *X1, *Hf, *Zffn, *X2;
+};
+struct FusedFwdArgs {
+    const float* x; const float* log_mask; const float* pos; const float* ln0g; const float* ln0b;
+    float* Z0; float* X0; float* y;
+    FusedBlk blk[8];
+    int64_t B; int32_t S, H, blocks, G;       // G sequences per workgroup
+    uint64_t seed; uint32_t thr24; float inv_keep;
+    long long* stamps;                        // development aid: cycle stamps of workgroup 0 at the stage boundaries (null in the product)
+};
+
+__device__ __forceinline__ float dropf(const FusedFwdArgs& a, uint32_t site, uint64_t idx) {
+    return a.thr24 ? drop_scale(a.seed, site, idx, a.thr24, a.inv_keep) : 1.0f;
+}
+
+// acc[rt] (+)= X[16 rt .. +15, 0..63] . W[n0 .. n0+15, 0..63]^T   (X: LDS image, W: global, row stride ldw floats).  The weight
+// fragment (four 16-byte loads per lane, L2) is requested by load_w() ahead of time — a product that waits for its own loads spends
+// ~1,000 of its ~2,900 cycles there (stage timeline) — and consumed by tile_product_w().
+struct WFrag { f4 v[4]; };
+__device__ __forceinline__ WFrag load_w(const float* __restrict__ W, int ldw, int n0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    WFrag w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w.v[t] = *(const f4*)(W + (int64_t)(n0 + i) * ldw + 16 * t + 4 * g);
+    return w;
+}
+__device__ __forceinline__ void tile_product_w(const float* __restrict__ X, const WFrag& w, int lane, f4 (&acc)[FNT]) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f4 xa[FNT];
+#pragma unroll
+        for (int rt = 0; rt < FNT; ++rt) xa[rt] = *(const f4*)(X + (16 * rt + i) * FLD + 16 * t + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)          // consecutive MFMAs on DIFFERENT accumulators (40-cycle dependent latency, 32-cycle issue)
+#pragma unroll
+            for (int rt = 0; rt < FNT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rt][e], w.v[t][e], acc[rt], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tile_product(const float* __restrict__ X, const float* __restrict__ W, int ldw, int n0, int lane,
+                                             f4 (&acc)[FNT]) {
+    tile_product_w(X, load_w(W, ldw, n0, lane), lane, acc);
+}
+__device__ __forceinline__ void zero_acc(f4 (&acc)[FNT]) {
+#pragma unroll
+    for (int rt = 0; rt < FNT; ++rt) acc[rt] = (f4){0.f, 0.f, 0.f, 0.f};
+}
+// accumulator element r of lane (j, g) in row tile rt is (row 16 rt + 4 g + r, column n0 + j)
+template <typename F>
+__device__ __forceinline__ void for_acc(const f4 (&acc)[FNT], int n0, int lane, F&& f) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < FNT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f(16 * rt + 4 * g + r, n0 + j, acc[rt][r]);
+}
+// LDS tile rows [0, nrows) x 64 -> global rows row0 .. (row stride ld floats, column offset c0), 16 bytes per thread and piece
+__device__ __forceinline__ void store_tile(const float* buf, float* gp, int64_t row0, int ld, int c0, int nrows, int tid) {
+    for (int p = tid; p < nrows * 16; p += 256) {
+        const int r = p >> 4, c = (p & 15) * 4;
+        *(f4*)(gp + (row0 + r) * ld + c0 + c) = *(const f4*)(buf + r * FLD + c);
+    }
+}
+// y = LN(z) * g + b over the 64 columns of rows [0, nrows): a wave takes FOUR rows at a time (16 lanes per row, 4 columns per lane,
+// two 4-step xor reductions) — one row per wave and pass was a serial chain of ~1,000 cycles per row (stage timeline: 21k cycles
+// per LayerNorm of 80 rows)
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void ln_rows(const float* z, float* y, const float* __restrict__ g, const float* __restrict__ b,
+                                        int nrows, int wave, int lane) {
+    const int c = (lane & 15) * 4;
+    const f4 gg = *(const f4*)(g + c), bb = *(const f4*)(b + c);
+    for (int r = wave * 4 + (lane >> 4); r < nrows; r += 16) {           // (rows past nrows: the whole 16-lane group skips)
+        const f4 v = *(const f4*)(z + r * FLD + c);
+        const float mean = sum16(v[0] + v[1] + v[2] + v[3]) * (1.0f / 64.0f);
+        const f4 d = v - mean;
+        const float rstd = rsqrtf(sum16(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 64.0f) + 1e-6f);
+        *(f4*)(y + r * FLD + c) = d * rstd * gg + bb;
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void sasrec_fused_fwd_kernel(FusedFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* bX = sm;                      // block input / output
+    float* bA = bX + FR * FLD;           // Q -> C -> Hf chunk
+    float* bB = bA + FR * FLD;           // K -> Zattn -> Zffn
+    float* bC = bB + FR * FLD;           // V -> X1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S, H = a.H;
+    constexpr int dh = DH;
+    const int64_t b0 = (int64_t)blockIdx.x * a.G;
+    const int nseq = (int)((a.B - b0) < a.G ? (a.B - b0) : a.G);
+    const int R = nseq * S;
+    const int64_t row0 = b0 * S;
+    const int n0 = 16 * wave;
+    int nst = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nst++] = __builtin_readcyclecounter(); };
+    stamp();
+    // rows R .. FR-1 of every buffer are read by the MFMAs of the last row tile: keep them finite
+    for (int p = tid; p < 4 * (FR - R) * FLD; p += 256) {
+        const int bf = p / ((FR - R) * FLD), o = p - bf * ((FR - R) * FLD);
+        sm[bf * FR * FLD + R * FLD + o] = 0.f;
+    }
+    // ---- X0 = drop(LN(x + pos)) ----
+    for (int p = tid; p < R * 16; p += 256) {
+        const int r = p >> 4, c = (p & 15) * 4;
+        const f4 xv = *(const f4*)(a.x + (row0 + r) * FE + c), pv = *(const f4*)(a.pos + (r % S) * FE + c);
+        *(f4*)(bB + r * FLD + c) = xv + pv;
+    }
+    __syncthreads();
+    store_tile(bB, a.Z0, row0, FE, 0, R, tid);
+    ln_rows(bB, bX, a.ln0g, a.ln0b, R, wave, lane);
+    __syncthreads();
+    if (a.thr24) {
+        for (int p = tid; p < R * 64; p += 256) {
+            const int r = p >> 6, c = p & 63;
+            bX[r * FLD + c] *= dropf(a, 0, (uint64_t)((row0 + r) * FE + c));
+        }
+        __syncthreads();
+    }
+    store_tile(bX, a.X0, row0, FE, 0, R, tid);
+    stamp();       // 1: embedding LN done
+    const float temp = sqrtf((float)dh);
+    for (int l = 0; l < a.blocks; ++l) {
+        const FusedBlk& k = a.blk[l];
+        // ---- Q, K, V ----
+        {
+            const WFrag fq = load_w(k.wq, FE, n0, lane), fk = load_w(k.wk, FE, n0, lane), fv = load_w(k.wv, FE, n0, lane);
+            f4 acc[FNT];
+            zero_acc(acc); tile_product_w(bX, fq, lane, acc);
+            for_acc(acc, n0, lane, [&](int r, int c, float v) { bA[r * FLD + c] = v; });
+            zero_acc(acc); tile_product_w(bX, fk, lane, acc);
+            for_acc(acc, n0, lane, [&](int r, int c, float v) { bB[r * FLD + c] = v; });
+            zero_acc(acc); tile_product_w(bX, fv, lane, acc);
+            for_acc(acc, n0, lane, [&](int r, int c, float v) { bC[r * FLD + c] = v; });
+        }
+        __syncthreads();
+        stamp();   // QKV products
+        store_tile(bA, k.Q, row0, FE, 0, R, tid);
+        store_tile(bB, k.K, row0, FE, 0, R, tid);
+        store_tile(bC, k.V, row0, FE, 0, R, tid);
+        __syncthreads();                                  // (Q is overwritten in place by the attention threads)
+        // ---- attention: ONE THREAD per (sequence, head, query) — scores, softmax and P.V in registers (S <= 16, dh <= 64).  The thread
+        //      reads its own Q row slice and overwrites exactly that slice of bA with C, so no barrier separates the three steps.
+        //      (first version: scores / softmax / P.V as three barrier-separated loops over LDS with index divisions — 26k + 6k + 21k
+        //      cycles per block in the stage timeline)
+        if (tid < nseq * H * S) {
+            const int sh = tid / S, q = tid - sh * S;
+            const int sq = sh / H, h = sh - sq * H;
+            float* qrow = bA + (sq * S + q) * FLD + h * dh;
+            f4 qa[DH / 4];
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) qa[e] = *(const f4*)(qrow + 4 * e);
+            float sc[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                if (kk < S) {
+                    const float* kr = bB + (sq * S + kk) * FLD + h * dh;
+                    f4 kb[DH / 4];
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) kb[e] = *(const f4*)(kr + 4 * e);
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) { d += qa[e][0] * kb[e][0]; d += qa[e][1] * kb[e][1]; d += qa[e][2] * kb[e][2]; d += qa[e][3] * kb[e][3]; }
+                    const float m = (kk <= q && a.log_mask[(b0 + sq) * S + kk] != 0.f) ? 0.f : -1e9f;
+                    sc[kk] = d / temp + m;
+                    mx = fmaxf(mx, sc[kk]);
+                }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < S) { sc[kk] = expf(sc[kk] - mx); sum += sc[kk]; }
+            const int64_t gp = ((b0 * H + sh) * S + q) * S;            // ((b H + h) S + q) S with b = b0 + sq
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < S) {
+                    const float pr = sc[kk] / sum;
+                    k.P[gp + kk] = pr;                                  // probabilities BEFORE dropout are kept for the backward
+                    sc[kk] = pr * dropf(a, 1 + 3 * l, (uint64_t)(gp + kk));
+                }
+            f4 oc[DH / 4];
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) oc[e] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < S) {
+                    const float* vr = bC + (sq * S + kk) * FLD + h * dh;
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) oc[e] += sc[kk] * *(const f4*)(vr + 4 * e);
+                }
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) *(f4*)(qrow + 4 * e) = oc[e];
+        }
+        __syncthreads();
+        stamp();   // attention
+        store_tile(bA, k.C, row0, FE, 0, R, tid);
+        // ---- Zattn = X + drop(C Wfc^T) -> bB (K is dead);  X1 = LN(Zattn) -> bC (V is dead) ----
+        {
+            f4 acc[FNT];
+            zero_acc(acc); tile_product(bA, k.wfc, FE, n0, lane, acc);
+            for_acc(acc, n0, lane, [&](int r, int c, float v) {
+                bB[r * FLD + c] = bX[r * FLD + c] + v * dropf(a, 2 + 3 * l, (uint64_t)((row0 + r) * FE + c));
+            });
+        }
+        __syncthreads();
+        stamp();   // fc product
+        store_tile(bB, k.Zattn, row0, FE, 0, R, tid);
+        ln_rows(bB, bC, k.ln1g, k.ln1b, R, wave, lane);
+        __syncthreads();
+        stamp();   // LN1
+        store_tile(bC, k.X1, row0, FE, 0, R, tid);
+        // ---- FFN in four chunks of 64 hidden units: Hf_c = relu(X1 W1_c^T + b1_c) -> bA; out += Hf_c W2[:, c]^T ----
+        f4 out[FNT];
+        zero_acc(out);
+        WFrag f1 = load_w(k.w1, FE, n0, lane);
+#pragma unroll 1
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const WFrag f2 = load_w(k.w2 + c4 * 64, 4 * FE, n0, lane);          // in flight during the first product
+            f4 acc[FNT];
+            zero_acc(acc); tile_product_w(bC, f1, lane, acc);
+            if (c4 < 3) f1 = load_w(k.w1 + (int64_t)(c4 + 1) * 64 * FE, FE, n0, lane);       // the next chunk's, during the second product
+            const float bias1 = k.b1[c4 * 64 + n0 + (lane & 15)];      // the lane's column
+            if (c4) __syncthreads();                 // the previous chunk's readers are done with bA
+            for_acc(acc, n0, lane, [&](int r, int c, float v) { bA[r * FLD + c] = fmaxf(v + bias1, 0.f); });
+            __syncthreads();
+            store_tile(bA, k.Hf, row0, 4 * FE, c4 * 64, R, tid);
+            tile_product_w(bA, f2, lane, out);
+        }
+        // ---- Zffn = X1 + drop(out + b2) -> bB (Zattn is dead);  X2 = LN(Zffn) -> bX ----
+        const float bias2 = k.b2[n0 + (lane & 15)];
+        for_acc(out, n0, lane, [&](int r, int c, float v) {
+            bB[r * FLD + c] = bC[r * FLD + c] + (v + bias2) * dropf(a, 3 + 3 * l, (uint64_t)((row0 + r) * FE + c));
+        });
+        __syncthreads();
+        stamp();   // FFN
+        store_tile(bB, k.Zffn, row0, FE, 0, R, tid);
+        ln_rows(bB, bX, k.ln2g, k.ln2b, R, wave, lane);
+        __syncthreads();
+        stamp();   // LN2
+        store_tile(bX, l == a.blocks - 1 ? a.y : k.X2, row0, FE, 0, R, tid);
+    }
+}
+
+}  // namespace
+
+// The fused path covers the production configuration; anything else stays on the per-operator launches of sasrec.hip.
+static int g_sasrec_fused = 1;
+static long long* g_sasrec_stamps = nullptr;
+extern "C" void iisan_set_sasrec_stamps(void* p) { g_sasrec_stamps = (long long*)p; }
+extern "C" void iisan_set_sasrec_fused(int32_t on) { g_sasrec_fused = on; }
+bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg) {
+    return g_sasrec_fused && cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&
+           (cfg->heads == 1 || cfg->heads == 2 || cfg->heads == 4) && (FR / cfg->seq) * cfg->heads * cfg->seq <= 256 && cfg->blocks >= 1 && cfg->blocks <= 8;
+}
+
+struct SasFusedPtrs {              // filled by sasrec.hip from its own carve
+    float* Z0; float* X0;
+    float* Q[8]; float* K[8]; float* V[8]; float* P[8]; float* C[8]; float* Zattn[8]; float* X1[8]; float* Hf[8]; float* Zffn[8]; float* X2[8];
+};
+
+int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B, const void* const* params,
+                            float* y, const SasFusedPtrs& w, hipStream_t s) {
+    FusedFwdArgs a{};
+    auto W = [&](int i) { return (const float*)params[i]; };
+    a.x = x; a.log_mask = log_mask; a.pos = W(0); a.ln0g = W(1); a.ln0b = W(2);
+    a.Z0 = w.Z0; a.X0 = w.X0; a.y = y;
+    for (int l = 0; l < cfg->blocks; ++l) {
+        FusedBlk& k = a.blk[l];
+        const int p = 3 + 12 * l;
+        k.wq = W(p); k.wk = W(p + 1); k.wv = W(p + 2); k.wfc = W(p + 3); k.ln1g = W(p + 4); k.ln1b = W(p + 5);
+        k.w1 = W(p + 6); k.b1 = W(p + 7); k.w2 = W(p + 8); k.b2 = W(p + 9); k.ln2g = W(p + 10); k.ln2b = W(p + 11);
+        k.Q = w.Q[l]; k.K = w.K[l]; k.V = w.V[l]; k.P = w.P[l]; k.C = w.C[l]; k.Zattn = w.Zattn[l]; k.X1 = w.X1[l];
+        k.Hf = w.Hf[l]; k.Zffn = w.Zffn[l]; k.X2 = w.X2[l];
+    }
+    a.B = B; a.S = cfg->seq; a.H = cfg->heads; a.blocks = cfg->blocks; a.G = FR / cfg->seq;
+    const DropCfg d = make_drop(cfg->seed, 0, cfg->dropout);
+    a.seed = d.seed; a.thr24 = d.thr24; a.inv_keep = d.inv_keep;
+    a.stamps = g_sasrec_stamps;
+    const size_t lds = (size_t)(4 * FR * FLD) * sizeof(float);
+    const dim3 grid((unsigned)ceil_div(B, a.G));
+    switch (FE / cfg->heads) {
+        case 64: hipLaunchKernelGGL(sasrec_fused_fwd_kernel<64>, grid, dim3(256), lds, s, a); break;
+        case 32: hipLaunchKernelGGL(sasrec_fused_fwd_kernel<32>, grid, dim3(256), lds, s, a); break;
+        case 16: hipLaunchKernelGGL(sasrec_fused_fwd_kernel<16>, grid, dim3(256), lds, s, a); break;
+        default: iisan_set_error("sasrec_fused: head width %d not instantiated", FE / cfg->heads); return IISAN_EBADSHAPE;
+    }
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}

@@ -21,7 +21,13 @@ hipEvent_t take() {
 }
 }  // namespace
 
-bool iisan_timing_on() { return g_on == 1; }
+// Stream filter (bench.py, overlapped towers): with the text tower on a second HIP stream its launches queue for compute units
+// behind the image tower's, and the span between their events is waiting, not running — only the launches on the filter stream
+// (the caller's main stream: the ViT tower, 87 % of the encoder GEMM FLOPs) are then a kernel measure.  null = every stream.
+static hipStream_t g_only = nullptr;
+static bool g_filter = false;
+extern "C" void iisan_timing_only_stream(void* stream, int32_t on) { g_only = (hipStream_t)stream; g_filter = on != 0; }
+bool iisan_timing_on(hipStream_t s) { return g_on == 1 && (!g_filter || s == g_only); }
 int iisan_timing_class() { return g_on; }
 void iisan_timing_pre(hipStream_t s, double flops, double bytes) {
     Rec r{take(), take(), flops, bytes};
