@@ -26,6 +26,9 @@ struct SasFusedPtrs {
 bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg);
 int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B, const void* const* params,
                             float* y, const SasFusedPtrs& w, hipStream_t s);
+int64_t sasrec_fused_slab_floats(const iisan_sasrec_cfg* cfg, int64_t B);
+int launch_sasrec_fused_bwd(const iisan_sasrec_cfg* cfg, const float* log_mask, int64_t B, const void* const* params, const float* dy,
+                            float* dx, void* const* grads, const SasFusedPtrs& w, float* slab, hipStream_t s);
 
 namespace {
 
@@ -255,6 +258,7 @@ struct SasBufs {
     float* X0;              // LN(Z0)
     BlockBufs blk[8];
     float *dA, *dB, *dQ, *dK, *dV, *dH, *dG;     // backward scratch
+    float* slab;            // fused backward: per-workgroup partial parameter gradients (carved last)
 };
 
 void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
@@ -272,6 +276,7 @@ void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
     b.dQ = c.take<float>(T * E); b.dK = c.take<float>(T * E); b.dV = c.take<float>(T * E);
     b.dH = c.take<float>(T * 4 * E);
     b.dG = c.take<float>(T * E);
+    b.slab = sasrec_fused_ok(cfg) ? c.take<float>((size_t)sasrec_fused_slab_floats(cfg, B)) : nullptr;
 }
 
 int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {
@@ -379,6 +384,8 @@ extern "C" int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, con
         iisan_set_error("sasrec_bwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
     }
+    if (sasrec_fused_ok(cfg) && b.slab)
+        return launch_sasrec_fused_bwd(cfg, log_mask, B, params, dy, dx, grads, fused_ptrs(b, cfg->blocks), b.slab, s);
     const int S = cfg->seq, E = cfg->emb, H = cfg->heads, dh = E / H;
     const int64_t T = B * S;
     auto W = [&](int i) { return (const float*)params[i]; };

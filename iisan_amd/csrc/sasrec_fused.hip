@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void sasrec_fused_fwd_kernel(FusedFwdArgs a) {
     store_tile(bX, a.X0, row0, FE, 0, R, tid);
     stamp();       // 1: embedding LN done
     const float temp = sqrtf((float)dh);
+#pragma unroll 1
     for (int l = 0; l < a.blocks; ++l) {
         const FusedBlk& k = a.blk[l];
         // ---- Q, K, V ----
@@ -274,6 +275,339 @@ __global__ __launch_bounds__(256) void sasrec_fused_fwd_kernel(FusedFwdArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// backward: the same row partition; parameter gradients leave as one slab of partial sums per workgroup (reduced by
+// sasrec_reduce_kernel in a fixed order: bit-reproducible, no atomics)
+// =====================================================================================================================
+struct FusedBwdArgs {
+    const float* dy; const float* log_mask; float* dx;
+    const float* Z0; const float* X0; const float* ln0g;
+    FusedBlk blk[8];
+    float* slab; int64_t slab_stride;
+    int64_t B; int32_t S, H, blocks, G;
+    uint64_t seed; uint32_t thr24; float inv_keep;
+};
+// slab layout (floats): [0, 1024) dpos | 1024 dln0.g | 1088 dln0.b | 1152 + l * SLAB_BLK: one block's gradients
+constexpr int SLAB_POS = 0, SLAB_LN0G = 1024, SLAB_LN0B = 1088, SLAB_BLK0 = 1152;
+constexpr int SB_WQ = 0, SB_WK = 4096, SB_WV = 8192, SB_WFC = 12288, SB_LN1G = 16384, SB_LN1B = 16448, SB_W1 = 16512, SB_B1 = 32896,
+              SB_W2 = 33152, SB_B2 = 49536, SB_LN2G = 49600, SB_LN2B = 49664, SLAB_BLK = 49728;
+
+__device__ __forceinline__ float dropb(const FusedBwdArgs& a, uint32_t site, uint64_t idx) {
+    return a.thr24 ? drop_scale(a.seed, site, idx, a.thr24, a.inv_keep) : 1.0f;
+}
+// weight fragment for a product that contracts over the ROWS of W:  B[k][j] = W[k * ld + n0 + j]  (dX = dY . W)
+__device__ __forceinline__ WFrag load_wT(const float* __restrict__ W, int ld, int n0, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    WFrag w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w.v[t][e] = W[(int64_t)(16 * t + 4 * g + e) * ld + n0 + j];
+    return w;
+}
+// global rows -> LDS tile (rows [0, nrows) x 64; pad rows are never written by anyone and stay zero)
+__device__ __forceinline__ void load_tile(float* buf, const float* gp, int64_t row0, int ld, int c0, int nrows, int tid) {
+    for (int p = tid; p < nrows * 16; p += 256) {
+        const int r = p >> 4, c = (p & 15) * 4;
+        *(f4*)(buf + r * FLD + c) = *(const f4*)(gp + (row0 + r) * ld + c0 + c);
+    }
+}
+// dW[i0 + .., 0..63] = A[:, i0 + ..]^T . B   (contraction over the FR rows of two LDS tiles; A's pad rows are zero).  Wave w owns
+// output rows 16 w ..+15 and all four column tiles; results go to dst[(row) * ldd + col].
+__device__ __forceinline__ void tile_dw(const float* A, const float* Bm, float* dst, int ldd, int wave, int lane) {
+    const int i = lane & 15, g = lane >> 4, i0 = 16 * wave;
+    f4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < FNT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kr = (16 * t + 4 * g + e) * FLD;
+            const float av = A[kr + i0 + i];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bm[kr + 16 * ct + i], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(int64_t)(i0 + 4 * g + r) * ldd + 16 * ct + i] = acc[ct][r];
+}
+// column sums over the rows of an LDS tile -> dst[0..63]
+__device__ __forceinline__ void tile_colsum(const float* buf, float* dst, int nrows, int tid) {
+    if (tid < 64) {
+        float s = 0.f;
+        for (int r = 0; r < nrows; ++r) s += buf[r * FLD + tid];
+        dst[tid] = s;
+    }
+}
+// LayerNorm backward over rows [0, nrows) of z (pre-norm input) with upstream dy (optionally times the embedding dropout factors):
+// dz -> out;  partial dgamma / dbeta of the workgroup -> dg[0..63], db[0..63] (through sRed[2][4][64])
+__device__ __forceinline__ void ln_bwd_rows(const FusedBwdArgs& a, const float* z, const float* dy, const float* __restrict__ g,
+                                            float* out, float* dgo, float* dbo, float* sRed, int nrows, int64_t row0, bool drop0,
+                                            int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = (lane & 15) * 4;
+    const f4 gg = *(const f4*)(g + c);
+    f4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    for (int r = wave * 4 + (lane >> 4); r < nrows; r += 16) {
+        const f4 v = *(const f4*)(z + r * FLD + c);
+        f4 d = *(const f4*)(dy + r * FLD + c);
+        if (drop0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] *= dropb(a, 0, (uint64_t)((row0 + r) * FE + c + e));
+        }
+        const float mean = sum16(v[0] + v[1] + v[2] + v[3]) * (1.0f / 64.0f);
+        const f4 vc = v - mean;
+        const float rstd = rsqrtf(sum16(vc[0] * vc[0] + vc[1] * vc[1] + vc[2] * vc[2] + vc[3] * vc[3]) * (1.0f / 64.0f) + 1e-6f);
+        const f4 xh = vc * rstd;
+        dg += d * xh;
+        db += d;
+        const f4 dgm = d * gg;
+        const float s1 = sum16(dgm[0] + dgm[1] + dgm[2] + dgm[3]) * (1.0f / 64.0f);
+        const float s2 = sum16(dgm[0] * xh[0] + dgm[1] * xh[1] + dgm[2] * xh[2] + dgm[3] * xh[3]) * (1.0f / 64.0f);
+        *(f4*)(out + r * FLD + c) = rstd * (dgm - s1 - xh * s2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        dg[e] += __shfl_xor(dg[e], 16, 64); dg[e] += __shfl_xor(dg[e], 32, 64);
+        db[e] += __shfl_xor(db[e], 16, 64); db[e] += __shfl_xor(db[e], 32, 64);
+    }
+    if (lane < 16) {
+        *(f4*)(sRed + wave * 64 + c) = dg;
+        *(f4*)(sRed + 256 + wave * 64 + c) = db;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        dgo[tid] = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
+        dbo[tid] = (sRed[256 + tid] + sRed[320 + tid]) + (sRed[384 + tid] + sRed[448 + tid]);
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void sasrec_fused_bwd_kernel(FusedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TB = FR * FLD;
+    float* bG = sm;              // incoming gradient of the block output / outgoing gradient of its input
+    float* bZ = bG + TB;         // forward tensor of the LayerNorm being differentiated
+    float* bA = bZ + TB;         // dZ (LayerNorm backward output)
+    float* bF = bA + TB;         // dZ times the dropout factors of the branch
+    float* bX = bF + TB;         // X1, later the block input
+    float* bH = bX + TB;         // Hf chunk / C / Q
+    float* bD = bH + TB;         // dHf chunk / dC
+    float* bK = bD + TB;         // K -> dK
+    float* bV = bK + TB;         // V -> dV
+    float* bQ = bF;              // dQ (the branch gradient is dead by then)
+    float* sS = bV + TB;         // dS   [attention threads <= 192][16]
+    float* sM = sS + 192 * 16;   // P * dropout factors
+    float* sRed = sM + 192 * 16; // [2][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S, H = a.H;
+    constexpr int dh = DH;
+    const int64_t b0 = (int64_t)blockIdx.x * a.G;
+    const int nseq = (int)((a.B - b0) < a.G ? (a.B - b0) : a.G);
+    const int R = nseq * S;
+    const int64_t row0 = b0 * S;
+    const int n0 = 16 * wave;
+    float* slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    const float temp = sqrtf((float)dh);
+    const bool drop = a.thr24 != 0;
+    // pad rows of every tile: zero, and never written afterwards (they are the tail of the K = rows contractions)
+    for (int p = tid; p < 9 * TB; p += 256) sm[p] = 0.f;
+    __syncthreads();
+    load_tile(bG, a.dy, row0, FE, 0, R, tid);
+    // guarded accumulator store: rows < R only
+    auto put = [&](float* buf, const f4 (&acc)[FNT], auto&& f) {
+        const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int rt = 0; rt < FNT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + 4 * g + r;
+                if (row < R) buf[row * FLD + n0 + j] = f(row, n0 + j, acc[rt][r]);
+            }
+    };
+#pragma unroll 1
+    for (int l = a.blocks - 1; l >= 0; --l) {
+        const FusedBlk& k = a.blk[l];
+        float* sb = slab + SLAB_BLK0 + l * SLAB_BLK;
+        // ---- X2 = LN(Zffn): dZffn -> bA ----
+        load_tile(bZ, k.Zffn, row0, FE, 0, R, tid);
+        load_tile(bX, k.X1, row0, FE, 0, R, tid);
+        __syncthreads();
+        ln_bwd_rows(a, bZ, bG, k.ln2g, bA, sb + SB_LN2G, sb + SB_LN2B, sRed, R, row0, false, tid);
+        __syncthreads();
+        // the FFN branch sees dZffn times the forward keep factors (Zffn = X1 + drop(Hf W2^T + b2))
+        const float* gF = bA;
+        if (drop) {
+            for (int p = tid; p < R * 64; p += 256) {
+                const int r = p >> 6, c = p & 63;
+                bF[r * FLD + c] = bA[r * FLD + c] * dropb(a, 3 + 3 * l, (uint64_t)((row0 + r) * FE + c));
+            }
+            gF = bF;
+            __syncthreads();
+        }
+        tile_colsum(gF, sb + SB_B2, R, tid);
+        f4 dx1[FNT];
+        zero_acc(dx1);
+#pragma unroll 1
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const WFrag f2 = load_wT(k.w2 + c4 * 64, 4 * FE, n0, lane);
+            const WFrag f1 = load_wT(k.w1 + (int64_t)c4 * 64 * FE, FE, n0, lane);
+            load_tile(bH, k.Hf, row0, 4 * FE, c4 * 64, R, tid);
+            f4 acc[FNT];
+            zero_acc(acc); tile_product_w(gF, f2, lane, acc);                  // gF . W2[:, chunk]
+            __syncthreads();                                                    // Hf chunk landed; bD free (previous chunk's readers done)
+            put(bD, acc, [&](int r, int c, float v) { return bH[r * FLD + c] > 0.f ? v : 0.f; });      // dHf = (.) * [Hf > 0]
+            __syncthreads();
+            tile_dw(gF, bH, sb + SB_W2 + c4 * 64, 4 * FE, wave, lane);         // dW2[:, chunk] = gF^T Hf
+            tile_dw(bD, bX, sb + SB_W1 + c4 * 64 * FE, FE, wave, lane);        // dW1[chunk, :] = dHf^T X1
+            tile_colsum(bD, sb + SB_B1 + c4 * 64, R, tid);
+            tile_product_w(bD, f1, lane, dx1);                                  // dX1 += dHf . W1[chunk, :]
+            __syncthreads();                                                    // bH / bD are rewritten by the next chunk
+        }
+        put(bG, dx1, [&](int r, int c, float v) { return bA[r * FLD + c] + v; });      // dX1 = dZffn + sum
+        // ---- X1 = LN(Zattn): dZattn -> bA ----
+        load_tile(bZ, k.Zattn, row0, FE, 0, R, tid);
+        load_tile(bH, k.C, row0, FE, 0, R, tid);
+        __syncthreads();
+        ln_bwd_rows(a, bZ, bG, k.ln1g, bA, sb + SB_LN1G, sb + SB_LN1B, sRed, R, row0, false, tid);
+        __syncthreads();
+        const float* gA = bA;
+        if (drop) {
+            for (int p = tid; p < R * 64; p += 256) {
+                const int r = p >> 6, c = p & 63;
+                bF[r * FLD + c] = bA[r * FLD + c] * dropb(a, 2 + 3 * l, (uint64_t)((row0 + r) * FE + c));
+            }
+            gA = bF;
+            __syncthreads();
+        }
+        // ---- Zattn = xin + drop(C Wfc^T): dC = gA . Wfc -> bD;  dWfc = gA^T C ----
+        {
+            const WFrag ff = load_wT(k.wfc, FE, n0, lane);
+            f4 acc[FNT];
+            zero_acc(acc); tile_product_w(gA, ff, lane, acc);
+            put(bD, acc, [&](int, int, float v) { return v; });
+            tile_dw(gA, bH, sb + SB_WFC, FE, wave, lane);
+        }
+        __syncthreads();
+        load_tile(bH, k.Q, row0, FE, 0, R, tid);
+        load_tile(bK, k.K, row0, FE, 0, R, tid);
+        load_tile(bV, k.V, row0, FE, 0, R, tid);
+        const float* xin = l == 0 ? a.X0 : a.blk[l - 1].X2;     // the block input: drop(LN(Z0)) or the previous block's output
+        __syncthreads();
+        // ---- attention backward, phase 1: one thread per (sequence, head, query) — dP, dS, dQ ----
+        if (tid < nseq * H * S) {
+            const int sh = tid / S, q = tid - sh * S;
+            const int sq = sh / H, h = sh - sq * H;
+            const int64_t gp = ((b0 * H + sh) * S + q) * S;
+            f4 dc[DH / 4];
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) dc[e] = *(const f4*)(bD + (sq * S + q) * FLD + h * dh + 4 * e);
+            float pr[16], dP[16];
+            float dot = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < S) {
+                    const float* vr = bV + (sq * S + kk) * FLD + h * dh;
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) {
+                        const f4 vv = *(const f4*)(vr + 4 * e);
+                        d += dc[e][0] * vv[0]; d += dc[e][1] * vv[1]; d += dc[e][2] * vv[2]; d += dc[e][3] * vv[3];
+                    }
+                    const float mk = dropb(a, 1 + 3 * l, (uint64_t)(gp + kk));
+                    pr[kk] = k.P[gp + kk];
+                    dP[kk] = d * mk;
+                    sM[tid * 16 + kk] = pr[kk] * mk;
+                    dot += pr[kk] * dP[kk];
+                }
+            f4 dq[DH / 4];
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) dq[e] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < S) {
+                    const float ds = pr[kk] * (dP[kk] - dot) / temp;
+                    sS[tid * 16 + kk] = ds;
+                    const float* kr = bK + (sq * S + kk) * FLD + h * dh;
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) dq[e] += ds * *(const f4*)(kr + 4 * e);
+                }
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) *(f4*)(bQ + (sq * S + q) * FLD + h * dh + 4 * e) = dq[e];
+        }
+        __syncthreads();
+        // ---- phase 2: one thread per (sequence, head, key) — dK = dS^T Q, dV = (P * mask)^T dC, in place over K / V ----
+        if (tid < nseq * H * S) {
+            const int sh = tid / S, kk = tid - sh * S;
+            const int sq = sh / H, h = sh - sq * H;
+            f4 dk[DH / 4], dv[DH / 4];
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) { dk[e] = (f4){0.f, 0.f, 0.f, 0.f}; dv[e] = (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < S) {
+                    const float ds = sS[(sh * S + q) * 16 + kk], pm = sM[(sh * S + q) * 16 + kk];
+                    const float* qr = bH + (sq * S + q) * FLD + h * dh;
+                    const float* cr = bD + (sq * S + q) * FLD + h * dh;
+#pragma unroll
+                    for (int e = 0; e < DH / 4; ++e) { dk[e] += ds * *(const f4*)(qr + 4 * e); dv[e] += pm * *(const f4*)(cr + 4 * e); }
+                }
+#pragma unroll
+            for (int e = 0; e < DH / 4; ++e) {
+                *(f4*)(bK + (sq * S + kk) * FLD + h * dh + 4 * e) = dk[e];
+                *(f4*)(bV + (sq * S + kk) * FLD + h * dh + 4 * e) = dv[e];
+            }
+        }
+        load_tile(bX, xin, row0, FE, 0, R, tid);
+        __syncthreads();
+        tile_dw(bQ, bX, sb + SB_WQ, FE, wave, lane);
+        tile_dw(bK, bX, sb + SB_WK, FE, wave, lane);
+        tile_dw(bV, bX, sb + SB_WV, FE, wave, lane);
+        {
+            const WFrag fq = load_wT(k.wq, FE, n0, lane), fk = load_wT(k.wk, FE, n0, lane), fv = load_wT(k.wv, FE, n0, lane);
+            f4 acc[FNT];
+            zero_acc(acc);
+            tile_product_w(bQ, fq, lane, acc);
+            tile_product_w(bK, fk, lane, acc);
+            tile_product_w(bV, fv, lane, acc);
+            put(bG, acc, [&](int r, int c, float v) { return bA[r * FLD + c] + v; });     // dxin = dZattn + dQ Wq + dK Wk + dV Wv
+        }
+        __syncthreads();
+    }
+    // ---- X0 = drop(LN(Z0)), Z0 = x + pos: dx, dln0, dpos ----
+    load_tile(bZ, a.Z0, row0, FE, 0, R, tid);
+    __syncthreads();
+    ln_bwd_rows(a, bZ, bG, a.ln0g, bA, slab + SLAB_LN0G, slab + SLAB_LN0B, sRed, R, row0, drop, tid);
+    __syncthreads();
+    store_tile(bA, a.dx, row0, FE, 0, R, tid);
+    for (int p = tid; p < S * 64; p += 256) {
+        const int sp = p >> 6, c = p & 63;
+        float s = 0.f;
+        for (int sq = 0; sq < nseq; ++sq) s += bA[(sq * S + sp) * FLD + c];
+        slab[SLAB_POS + p] = s;
+    }
+}
+
+// grads[i][e] += sum over workgroups of slab[wg][off_i + e]   (ascending workgroup order: reproducible)
+struct ReduceTab { float* g[100]; int32_t off[100]; int32_t cnt[100]; int32_t n; };
+__global__ __launch_bounds__(256) void sasrec_reduce_kernel(const float* __restrict__ slab, int64_t stride, int nwg, ReduceTab t) {
+    const int i = blockIdx.y;
+    if (i >= t.n) return;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < t.cnt[i]; e += gridDim.x * 256) {
+        const float* p = slab + t.off[i] + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int w = 0;
+        for (; w + 4 <= nwg; w += 4) {
+            s0 += p[(int64_t)w * stride]; s1 += p[(int64_t)(w + 1) * stride]; s2 += p[(int64_t)(w + 2) * stride]; s3 += p[(int64_t)(w + 3) * stride];
+        }
+        for (; w < nwg; ++w) s0 += p[(int64_t)w * stride];
+        t.g[i][e] += (s0 + s1) + (s2 + s3);
+    }
+}
+
 }  // namespace
 
 // The fused path covers the production configuration; anything else stays on the per-operator launches of sasrec.hip.
@@ -284,6 +618,10 @@ extern "C" void iisan_set_sasrec_fused(int32_t on) { g_sasrec_fused = on; }
 bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg) {
     return g_sasrec_fused && cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&
            (cfg->heads == 1 || cfg->heads == 2 || cfg->heads == 4) && (FR / cfg->seq) * cfg->heads * cfg->seq <= 256 && cfg->blocks >= 1 && cfg->blocks <= 8;
+}
+
+int64_t sasrec_fused_slab_floats(const iisan_sasrec_cfg* cfg, int64_t B) {
+    return ceil_div(B, FR / cfg->seq) * (int64_t)(SLAB_BLK0 + cfg->blocks * SLAB_BLK);
 }
 
 struct SasFusedPtrs {              // filled by sasrec.hip from its own carve
@@ -317,6 +655,49 @@ int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const f
         case 16: hipLaunchKernelGGL(sasrec_fused_fwd_kernel<16>, grid, dim3(256), lds, s, a); break;
         default: iisan_set_error("sasrec_fused: head width %d not instantiated", FE / cfg->heads); return IISAN_EBADSHAPE;
     }
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+int launch_sasrec_fused_bwd(const iisan_sasrec_cfg* cfg, const float* log_mask, int64_t B, const void* const* params, const float* dy,
+                            float* dx, void* const* grads, const SasFusedPtrs& w, float* slab, hipStream_t s) {
+    FusedBwdArgs a{};
+    auto W = [&](int i) { return (const float*)params[i]; };
+    a.dy = dy; a.log_mask = log_mask; a.dx = dx; a.Z0 = w.Z0; a.X0 = w.X0; a.ln0g = W(1);
+    ReduceTab tab{};
+    auto add = [&](int pi, int off, int cnt) { tab.g[tab.n] = (float*)grads[pi]; tab.off[tab.n] = off; tab.cnt[tab.n] = cnt; ++tab.n; };
+    add(0, SLAB_POS, cfg->seq * FE); add(1, SLAB_LN0G, FE); add(2, SLAB_LN0B, FE);
+    for (int l = 0; l < cfg->blocks; ++l) {
+        FusedBlk& k = a.blk[l];
+        const int p = 3 + 12 * l, o = SLAB_BLK0 + l * SLAB_BLK;
+        k.wq = W(p); k.wk = W(p + 1); k.wv = W(p + 2); k.wfc = W(p + 3); k.ln1g = W(p + 4); k.ln1b = W(p + 5);
+        k.w1 = W(p + 6); k.b1 = W(p + 7); k.w2 = W(p + 8); k.b2 = W(p + 9); k.ln2g = W(p + 10); k.ln2b = W(p + 11);
+        k.Q = w.Q[l]; k.K = w.K[l]; k.V = w.V[l]; k.P = w.P[l]; k.C = w.C[l]; k.Zattn = w.Zattn[l]; k.X1 = w.X1[l];
+        k.Hf = w.Hf[l]; k.Zffn = w.Zffn[l]; k.X2 = w.X2[l];
+        add(p, o + SB_WQ, 4096); add(p + 1, o + SB_WK, 4096); add(p + 2, o + SB_WV, 4096); add(p + 3, o + SB_WFC, 4096);
+        add(p + 4, o + SB_LN1G, 64); add(p + 5, o + SB_LN1B, 64); add(p + 6, o + SB_W1, 16384); add(p + 7, o + SB_B1, 256);
+        add(p + 8, o + SB_W2, 16384); add(p + 9, o + SB_B2, 64); add(p + 10, o + SB_LN2G, 64); add(p + 11, o + SB_LN2B, 64);
+    }
+    a.slab = slab; a.slab_stride = SLAB_BLK0 + cfg->blocks * SLAB_BLK;
+    a.B = B; a.S = cfg->seq; a.H = cfg->heads; a.blocks = cfg->blocks; a.G = FR / cfg->seq;
+    const DropCfg d = make_drop(cfg->seed, 0, cfg->dropout);
+    a.seed = d.seed; a.thr24 = d.thr24; a.inv_keep = d.inv_keep;
+    const size_t lds = (size_t)(9 * FR * FLD + 2 * 192 * 16 + 512) * sizeof(float);
+    const int nwg = (int)ceil_div(B, a.G);
+    static OncePerDevice attr;
+    if (attr.first()) {
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)sasrec_fused_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)sasrec_fused_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        IISAN_HIP_OK(hipFuncSetAttribute((const void*)sasrec_fused_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    switch (FE / cfg->heads) {
+        case 64: hipLaunchKernelGGL(sasrec_fused_bwd_kernel<64>, dim3(nwg), dim3(256), lds, s, a); break;
+        case 32: hipLaunchKernelGGL(sasrec_fused_bwd_kernel<32>, dim3(nwg), dim3(256), lds, s, a); break;
+        case 16: hipLaunchKernelGGL(sasrec_fused_bwd_kernel<16>, dim3(nwg), dim3(256), lds, s, a); break;
+        default: iisan_set_error("sasrec_fused: head width %d not instantiated", FE / cfg->heads); return IISAN_EBADSHAPE;
+    }
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(sasrec_reduce_kernel, dim3(16, tab.n), dim3(256), 0, s, slab, a.slab_stride, nwg, tab);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
