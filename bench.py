@@ -147,8 +147,10 @@ class Clock:
 def cached_pmc_traffic(a):
     """HBM-side bytes of one whole Cached / Versa step (all kernels) from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic_cached.json, written by tools/pmc_traffic.py --step); null unless this run is that configuration."""
+    from iisan_amd import _lib
     path = os.path.join(ROOT, "profiles", "pmc_traffic_cached.json")
-    if not os.path.exists(path) or a.dedup:
+    # the committed passes are of ONE configuration: a single rank, the library's own routes (no --x3 override, no dev knobs)
+    if not os.path.exists(path) or a.dedup or a.x3 != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1 or _lib.dev_knobs():
         return None
     with open(path) as f:
         d = json.load(f)
@@ -349,6 +351,12 @@ class Uncached:
         self.tr.broadcast_params()
         self.ids = self.batch.ids.view(-1)
 
+    def set_full_blocks(self, on):
+        """Dead-work policy of both towers through the weights structs' `full_blocks` field (include/iisan_hip.h)."""
+        enc = self.model.mm_encoder
+        enc.cv_encoder.full_blocks = bool(on)
+        enc.bert_encoder.text_encoders["title"].full_blocks = bool(on)
+
     def set_dtype(self, name):
         from iisan_amd import encoders
         enc = self.model.mm_encoder
@@ -370,7 +378,7 @@ class Uncached:
         enc = self.model.mm_encoder
         need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
         self.model.eval()
-        self.lib.iisan_set_full_blocks(1 if self.a.full_blocks else 0)
+        self.set_full_blocks(self.a.full_blocks)
         try:
             with torch.no_grad():
                 for v in (0, 1):
@@ -379,7 +387,7 @@ class Uncached:
                     taps[v] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
         finally:
             self.lib.iisan_set_gemm16_variant(0)
-            self.lib.iisan_set_full_blocks(0)
+            self.set_full_blocks(False)
             self.model.train()
         rel = abs(loss[0] - loss[1]) / abs(loss[1])
         tap_rel = 0.0
@@ -415,7 +423,7 @@ class Uncached:
     def line(self, steps, warmup, dtype="fp16", full_blocks=True, headline=True, overlap=None):
         a, lib, world = self.a, self.lib, self.world
         self.set_dtype(dtype)
-        lib.iisan_set_full_blocks(1 if full_blocks else 0)
+        self.set_full_blocks(full_blocks)
         enc = self.model.mm_encoder
         prev_overlap = enc.overlap_towers
         if overlap is not None:
@@ -434,7 +442,7 @@ class Uncached:
             else:
                 elapsed, loss = clock.run(self.step, warmup, steps, lib, timed=self.rank == 0)
         finally:
-            lib.iisan_set_full_blocks(0)
+            self.set_full_blocks(False)
             lib.iisan_timing_only_stream(None, 0)
             overlapped = enc.overlap_towers
             enc.overlap_towers = prev_overlap

@@ -23,14 +23,14 @@ class LayerWeights(C.Structure):
 
 class VitWeights(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("mlp", i32),
-                ("image", i32), ("patch", i32), ("channels", i32), ("dtype16", i32), ("eps", f32),
+                ("image", i32), ("patch", i32), ("channels", i32), ("dtype16", i32), ("eps", f32), ("full_blocks", i32),
                 ("patch_w", vp), ("patch_b", vp), ("cls_token", vp), ("pos_emb", vp),
                 ("layer", LayerWeights * MAX_LAYERS)]
 
 
 class BertWeights(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("mlp", i32),
-                ("vocab", i32), ("max_pos", i32), ("dtype16", i32), ("eps", f32),
+                ("vocab", i32), ("max_pos", i32), ("dtype16", i32), ("eps", f32), ("full_blocks", i32),
                 ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
                 ("layer", LayerWeights * MAX_LAYERS)]
 
@@ -59,23 +59,22 @@ SIGNATURES = {
     "iisan_bert_forward_taps": (i32, [C.POINTER(BertWeights), vp, i64, i32, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_side_net_ws_bytes": (sz, [C.POINTER(SideCfg), i64]),
     "iisan_side_net_num_params": (i32, [C.POINTER(SideCfg)]),
-    "iisan_side_net_fwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
-    "iisan_side_net_bwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, C.POINTER(vp), vp, sz, vp]),
+    "iisan_side_net_fwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, C.POINTER(u64), vp]),
+    "iisan_side_net_bwd": (i32, [C.POINTER(SideCfg), vp, vp, i64, C.POINTER(vp), vp, C.POINTER(vp), vp, sz, u64, vp]),
     "iisan_linear_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_linear_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_sasrec_ws_bytes": (sz, [C.POINTER(SasrecCfg), i64]),
     "iisan_sasrec_fwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, sz, vp]),
     "iisan_sasrec_bwd": (i32, [C.POINTER(SasrecCfg), vp, vp, i64, C.POINTER(vp), vp, vp, C.POINTER(vp), vp, sz, vp]),
     "iisan_inbatch_ce_ws_bytes": (sz, [i64, i32]),
-    "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, sz, vp]),
-    "iisan_inbatch_ce_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, sz, C.POINTER(u64), vp]),
+    "iisan_inbatch_ce_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, sz, u64, vp]),
     "iisan_score_rank": (i32, [vp, vp, i64, i64, i32, vp, i32, vp, vp, vp]),
     "iisan_adam_step": (i32, [vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(f32), i32, i32, f32, f32, f32, f32, vp]),
     "iisan_gemm16": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_layernorm768": (i32, [i32, vp, vp, vp, f32, vp, vp, i64, vp]),
     "iisan_attention16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_attention_cls16": (i32, [i32, vp, vp, vp, i64, i32, i32, vp]),
-    "iisan_set_full_blocks": (None, [i32]),
     "iisan_gemm32": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp]),
     "iisan_gemm_x3_ws_bytes": (sz, [i64, i32, i64]),
     "iisan_gemm_x3": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp, sz, vp]),
@@ -85,10 +84,12 @@ SIGNATURES = {
 
 # bench-only helpers (not declared in include/iisan_hip.h)
 EXTRA_SIGNATURES = {
+    "iisan_set_full_blocks": (None, [i32]),          # process-wide OVERRIDE of the weights structs' `full_blocks` field (tests, bench)
     "iisan_timing_enable": (None, [i32]),
     "iisan_timing_only_stream": (None, [vp, i32]),
     "iisan_set_gemm16_variant": (None, [i32]),
     "iisan_set_gemm16_walk": (None, [i32, i32]),
+    "iisan_gemm16_h256_applicable": (i32, [i32, i64, i32, i32, i32, i32, i32]),
     "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_gemm16_h256": (None, [i32]),

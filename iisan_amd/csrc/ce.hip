@@ -834,12 +834,16 @@ extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
     return c.off;
 }
 
+// the forward call's token: a tag, the call shape and the route it took
+static uint64_t ce_token(int64_t bs, int32_t S, int fused) {
+    return 0xCE00000000000000ull | ((uint64_t)(bs & 0xFFFFFFFFll) << 16) | ((uint64_t)(S & 0xFF) << 8) | (uint64_t)(fused ? 2 : 1);
+}
 extern "C" void iisan_set_ce_fast(int32_t on) { g_ce_fast = on; }
 extern "C" void iisan_set_ce_debug(int32_t bits) { g_ce_dbg = bits; }        // ablation bits of the fused row pass (timing only)
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,
-                                    void* ws, size_t ws_bytes, void* stream) {
+                                    void* ws, size_t ws_bytes, uint64_t* fwd_token, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     IISAN_TRY(check(bs, S, Ein));
     IISAN_CHECK_SHAPE(n_pop > 0, "inbatch_ce_fwd: empty pop_prob table");
@@ -856,8 +860,10 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();
     // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it — the
-    // route is noted under the workspace so that the backward call follows what THIS call did, not the knob's later value
-    iisan_route_note(ws, ROUTE_CE, (rowpass_ok(bs, S) && g_ce_fast == 1) ? 1 : 0);
+    // route goes back to the caller as a token, so that the backward call follows what THIS call did, not the knob's later
+    // value, and the library keeps no per-call state
+    IISAN_CHECK_SHAPE(fwd_token != nullptr, "inbatch_ce_fwd: fwd_token must not be null");
+    *fwd_token = ce_token(bs, S, (rowpass_ok(bs, S) && g_ce_fast == 1) ? 1 : 0);
     if (rowpass_ok(bs, S) && g_ce_fast == 1 && S + 1 <= 11)
         hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr, g_ce_dbg);
     else if (rowpass_ok(bs, S) && g_ce_fast == 1)
@@ -878,7 +884,7 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
 
 extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t bs, int32_t S, int32_t Ein, float d_loss, float* d_score,
-                                    float* d_prec, void* ws, size_t ws_bytes, void* stream) {
+                                    float* d_prec, void* ws, size_t ws_bytes, uint64_t fwd_token, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     IISAN_TRY(check(bs, S, Ein));
     WsCarver c(ws, ws_bytes);
@@ -889,9 +895,9 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    uint64_t fused = 0;
-    if (!iisan_route_find(ws, ROUTE_CE, &fused)) {
-        iisan_set_error("inbatch_ce_bwd: no inbatch_ce_fwd call has filled this workspace");
+    const bool fused = fwd_token == ce_token(bs, S, 1);
+    if (!fused && fwd_token != ce_token(bs, S, 0)) {
+        iisan_set_error("inbatch_ce_bwd: fwd_token %llx is not what inbatch_ce_fwd returns for bs = %lld, S = %d", (unsigned long long)fwd_token, (long long)bs, S);
         return IISAN_EBADSHAPE;
     }
     if (fused)        // d_prec for d_loss = 1 is in the workspace (whatever iisan_set_ce_fast says by now)

@@ -47,11 +47,6 @@ void iisan_set_error(const char* fmt, ...);
         if (_r != IISAN_OK) return _r;                                                                           \
     } while (0)
 
-// host-side note of the kernel route a forward call took on a workspace, read by its backward call (api.cpp)
-enum { ROUTE_CE = 1, ROUTE_SIDE_X3 = 2 };
-void iisan_route_note(const void* ws, uint32_t kind, uint64_t value);
-bool iisan_route_find(const void* ws, uint32_t kind, uint64_t* value);
-
 // per-device host caches (api.cpp).  iisan_cu_count(): compute units of the CURRENT device, asked of the runtime once per
 // device.  OncePerDevice: "this kernel's dynamic-LDS limit has been raised" is a fact about one device — a process that drives
 // a second device must raise it there too (a process-wide `static bool` made the second device's launches fail).

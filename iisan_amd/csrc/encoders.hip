@@ -78,7 +78,8 @@ int tap_index(const int32_t* tap_layers, int n, int layer) {
     return -1;
 }
 
-// ablation switch (bench.py --full-last-block, tests): 1 = run every block of the tower on every token, as the reference does
+// process-wide OVERRIDE of the weights structs' `full_blocks` field (bench.py, tests; not declared in include/iisan_hip.h):
+// 1 = run every block of the tower on every token, as the reference does
 int g_full_blocks = 0;
 
 int max_tap(const int32_t* tap_layers, int n) {
@@ -175,7 +176,8 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         // Blocks after the deepest tapped hidden state are dead code (Versa configurations tap a prefix of the tower),
         // and in the last LIVE block only the CLS token's output is consumed: K/V are computed for every token, but
         // attention, O, LN2, FC1, FC2 and the closing residual add run on one row per item.
-        const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);
+        const bool full_blocks = g_full_blocks || w->full_blocks;
+        const int live = full_blocks ? w->layers : max_tap(tap_layers, n_taps);
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // x += pending deltas of block l-1 ; h = LN1(x)            -> the stream is hidden state l
@@ -188,7 +190,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
             pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(tap(k));
-            if (l + 1 < live || g_full_blocks) {
+            if (l + 1 < live || full_blocks) {
                 IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
@@ -219,7 +221,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 IISAN_TRY(launch_gather_cls(Xc, tp, mc, 1, D, n_taps, k, s));
             }
         }
-        if (g_full_blocks) {
+        if (full_blocks) {
             k = tap_index(tap_layers, n_taps, w->layers);
             if (k >= 0) {
                 if (!mixed)
@@ -273,11 +275,12 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
         };
         int k = tap_index(tap_layers, n_taps, 0);
         if (k >= 0) IISAN_TRY(tap(k));
-        const int live = g_full_blocks ? w->layers : max_tap(tap_layers, n_taps);     // see the ViT executor
+        const bool full_blocks = g_full_blocks || w->full_blocks;
+        const int live = full_blocks ? w->layers : max_tap(tap_layers, n_taps);     // see the ViT executor
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // a = LN(x + O(attn(x)))
-            if (l + 1 < live || g_full_blocks) {
+            if (l + 1 < live || full_blocks) {
                 IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));

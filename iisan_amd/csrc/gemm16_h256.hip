@@ -642,11 +642,22 @@ bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
         return false;
     const int64_t rows = ceil_div(a.M, SBM) * SBM;
-    if (mode == EPI_QKVH16)      // 32-bit byte offsets into the head-major tensor, exact reciprocal division
-        return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && rows * (int64_t)(3 - a.qkv_which0) * a.qkv_heads * 128 < (1ll << 32);
+    if (mode == EPI_QKVH16)      // 32-bit byte offsets into the head-major tensor, exact reciprocal division.  The layout is always
+                                 // [item][head][q|k|v][S][64]: element-row index R reaches rows * 3 * heads WHATEVER qkv_which0 is (a
+                                 // K/V-only product of the CLS-pruned last block still addresses the full tensor) — ADVICE r3: the bound
+                                 // used (3 - which0) and let row counts in [932k, 1.40M) wrap at 12 heads
+        return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && rows * 3 * (int64_t)a.qkv_heads * 128 + 128 < (1ll << 32);
     return (int64_t)a.ldo * 2 * 16 + 64 < (1ll << 31);       // the 32-bit lane offset of a 16-row store
 }
 
 int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     return dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+}
+
+// host-side predicate, exported for the CPU tests (tests/test_host_logic.py): no device is touched
+extern "C" int32_t iisan_gemm16_h256_applicable(int32_t mode, int64_t M, int32_t N, int32_t K, int32_t qkv_S, int32_t qkv_heads,
+                                                int32_t qkv_which0) {
+    Gemm16Args a{};
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.qkv_S = qkv_S; a.qkv_heads = qkv_heads; a.qkv_which0 = qkv_which0;
+    return gemm16_h256_applicable(mode, a) ? 1 : 0;
 }

@@ -24,6 +24,7 @@ struct SasFusedPtrs {
     float* Q[8]; float* K[8]; float* V[8]; float* P[8]; float* C[8]; float* Zattn[8]; float* X1[8]; float* Hf[8]; float* Zffn[8]; float* X2[8];
 };
 bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg);
+bool sasrec_fused_shape_ok(const iisan_sasrec_cfg* cfg);
 int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B, const void* const* params,
                             float* y, const SasFusedPtrs& w, hipStream_t s);
 int64_t sasrec_fused_slab_floats(const iisan_sasrec_cfg* cfg, int64_t B);
@@ -276,7 +277,7 @@ void carve(WsCarver& c, SasBufs& b, const iisan_sasrec_cfg* cfg, int64_t B) {
     b.dQ = c.take<float>(T * E); b.dK = c.take<float>(T * E); b.dV = c.take<float>(T * E);
     b.dH = c.take<float>(T * 4 * E);
     b.dG = c.take<float>(T * E);
-    b.slab = sasrec_fused_ok(cfg) ? c.take<float>((size_t)sasrec_fused_slab_floats(cfg, B)) : nullptr;
+    b.slab = sasrec_fused_shape_ok(cfg) ? c.take<float>((size_t)sasrec_fused_slab_floats(cfg, B)) : nullptr;
 }
 
 int check_cfg(const iisan_sasrec_cfg* cfg, int64_t B) {

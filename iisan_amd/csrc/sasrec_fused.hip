@@ -615,10 +615,11 @@ static int g_sasrec_fused = 1;
 static long long* g_sasrec_stamps = nullptr;
 extern "C" void iisan_set_sasrec_stamps(void* p) { g_sasrec_stamps = (long long*)p; }
 extern "C" void iisan_set_sasrec_fused(int32_t on) { g_sasrec_fused = on; }
-bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg) {
-    return g_sasrec_fused && cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&
-           (cfg->heads == 1 || cfg->heads == 2 || cfg->heads == 4) && (FR / cfg->seq) * cfg->heads * cfg->seq <= 256 && cfg->blocks >= 1 && cfg->blocks <= 8;
+bool sasrec_fused_shape_ok(const iisan_sasrec_cfg* cfg) {       // (the workspace is sized by this alone: the knob only picks kernels)
+    return cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&
+           (cfg->heads == 1 || cfg->heads == 2 || cfg->heads == 4) && (FR / cfg->seq) * cfg->heads * cfg->seq <= 192 && cfg->blocks >= 1 && cfg->blocks <= 8;
 }
+bool sasrec_fused_ok(const iisan_sasrec_cfg* cfg) { return g_sasrec_fused && sasrec_fused_shape_ok(cfg); }
 
 int64_t sasrec_fused_slab_floats(const iisan_sasrec_cfg* cfg, int64_t B) {
     return ceil_div(B, FR / cfg->seq) * (int64_t)(SLAB_BLK0 + cfg->blocks * SLAB_BLK);

@@ -452,7 +452,8 @@ extern "C" int32_t iisan_side_net_num_params(const iisan_side_cfg* cfg) {
 }
 
 extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
-                                  const void* const* params, float* item3, void* ws, size_t ws_bytes, void* stream) {
+                                  const void* const* params, float* item3, void* ws, size_t ws_bytes, uint64_t* fwd_token,
+                                  void* stream) {
     hipStream_t s = (hipStream_t)stream;
     Ctx c;
     IISAN_TRY(setup(c, cfg, taps_cv, taps_text, M, params, ws, ws_bytes, "side_net_fwd"));
@@ -461,7 +462,8 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     ScratchGuard guard(b.skws, b.skws_floats);
     const int act_flag = cfg->gelu ? G32_GELU : G32_RELU;
     const int nsteps = p.diff_cv + p.diff_t + p.n[2];
-    iisan_route_note(ws, ROUTE_SIDE_X3, x3_route_word());     // the backward call must see the same split-operand routing
+    IISAN_CHECK_SHAPE(fwd_token != nullptr, "side_net_fwd: fwd_token must not be null");
+    *fwd_token = 0x51DE000000000000ull ^ x3_route_word();     // the backward call must see the same split-operand routing
     IISAN_HIP_OK(hipMemsetAsync(b.amax, 0, (size_t)(16 + IISAN_MAX_SIDE + X3Z_WORDS * X3Z_SLOTS_F) * sizeof(uint32_t), s));
     b.x3z_next = b.x3z_f; b.x3z_left = X3Z_SLOTS_F;
     // taps known to be exact in fp16 (cfg->taps_exact16): their amax slots are PRESET to 8192.0f, which the split kernels turn into
@@ -548,16 +550,15 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
 
 extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
                                   const void* const* params, const float* d_item3, void* const* grads, void* ws,
-                                  size_t ws_bytes, void* stream) {
+                                  size_t ws_bytes, uint64_t fwd_token, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     Ctx c;
     {   // (before setup(): a changed routing also changes the workspace layout.)  The amax slots this call marks "ready" were filled by the forward call only on the routes IT took
-        uint64_t fwd_route = 0;
-        if (!iisan_route_find(ws, ROUTE_SIDE_X3, &fwd_route)) {
-            iisan_set_error("side_net_bwd: no side_net_fwd call has filled this workspace");
+        if ((fwd_token >> 48) != 0x51DE) {
+            iisan_set_error("side_net_bwd: fwd_token %llx did not come from side_net_fwd", (unsigned long long)fwd_token);
             return IISAN_EBADSHAPE;
         }
-        if (fwd_route != x3_route_word()) {
+        if ((fwd_token ^ 0x51DE000000000000ull) != x3_route_word()) {
             iisan_set_error("side_net_bwd: the split-operand routing (iisan_set_x3) changed since side_net_fwd filled this workspace");
             return IISAN_EBADSHAPE;
         }

@@ -47,6 +47,15 @@ class _PackedEncoder:
         self.ws = _Workspace()
         self._w = w
 
+    # dead-work policy of the executor (include/iisan_hip.h): a field of the weights struct, i.e. part of every call
+    @property
+    def full_blocks(self) -> bool:
+        return bool(self.struct.full_blocks)
+
+    @full_blocks.setter
+    def full_blocks(self, on: bool):
+        self.struct.full_blocks = 1 if on else 0
+
     def _m16(self, name: str) -> int:      # matrix operand of an MFMA GEMM
         t = self._w[name].to(self.device, dtype=torch.float32).to(_TORCH16[self.dtype16]).contiguous()
         self._keep.append(t)

@@ -96,6 +96,9 @@ def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[i
     (`eval_seq`), `histories[u]` = items to exclude (`user_history`, metrics.py:204-205)."""
     U = len(eval_seqs)
     hs = max(1, max(len(h) for h in histories))
+    if hs > 256:       # iisan_score_rank keeps a user's exclusion list in LDS (include/iisan_hip.h: hist_stride <= 256)
+        raise ValueError(f"evaluate_ranks: the longest exclusion list has {hs} items; iisan_score_rank takes at most 256 per user "
+                         "(Scientific: <= 10 train items per user)")
     idx = dp.sequential_shard(U, rank, world, batch) if world > 1 else list(range(U))
     tok, lm, hist, tgt = _pack_users([eval_seqs[i] for i in idx], [histories[i] for i in idx], max_seq_len, hs)
     dev = item_emb.device

@@ -91,7 +91,9 @@ class Vit_Encoder(nn.Module):                      # encoders.py:23-31
     def forward_taps(self, item_content, tap_layers):
         """CLS rows of the requested hidden states, [M, len(tap_layers), 768] fp32 (no grad)."""
         with torch.no_grad():
-            return self.packed(item_content.device).forward_taps(item_content.contiguous(), list(tap_layers), self.chunk_items)
+            pk = self.packed(item_content.device)
+            pk.full_blocks = getattr(self, "full_blocks", False)      # True: every block on every token, like HF (bench.py)
+            return pk.forward_taps(item_content.contiguous(), list(tap_layers), self.chunk_items)
 
     def forward(self, item_content):
         """Reference signature (`encoders.py:29-31`).  Returns `(None, hidden_states)` where each hidden state is the
@@ -141,7 +143,9 @@ class Text_Encoder(nn.Module):                     # encoders.py:68-91
 
     def forward_taps(self, text, tap_layers):
         with torch.no_grad():
-            return self.packed(text.device).forward_taps(text.contiguous().to(torch.int64), list(tap_layers), self.chunk_items)
+            pk = self.packed(text.device)
+            pk.full_blocks = getattr(self, "full_blocks", False)
+            return pk.forward_taps(text.contiguous().to(torch.int64), list(tap_layers), self.chunk_items)
 
     def forward(self, text):
         L = self.packed(text.device).cfg.layers

@@ -162,9 +162,10 @@ class SideNetFn(torch.autograd.Function):
         item3 = torch.empty((M, 3 * cfg.emb), dtype=torch.float32, device=taps_cv.device)
         ws = torch.empty(lib.iisan_side_net_ws_bytes(C.byref(cfg), M), dtype=torch.uint8, device=taps_cv.device)
         tab = _ptr_table(params)
+        token = C.c_uint64(0)          # which kernel routes this forward took: carried to the backward call with the workspace
         _lib.check(lib.iisan_side_net_fwd(C.byref(cfg), taps_cv.data_ptr(), taps_text.data_ptr(), M, tab,
-                                          item3.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "iisan_side_net_fwd")
-        ctx.cfg, ctx.ws, ctx.params = cfg, ws, params
+                                          item3.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(token), _stream()), "iisan_side_net_fwd")
+        ctx.cfg, ctx.ws, ctx.params, ctx.token = cfg, ws, params, token.value
         ctx.save_for_backward(taps_cv, taps_text)
         return item3
 
@@ -177,7 +178,7 @@ class SideNetFn(torch.autograd.Function):
         views, ret = _grad_targets(ctx.orig)
         _lib.check(lib.iisan_side_net_bwd(C.byref(cfg), taps_cv.data_ptr(), taps_text.data_ptr(), taps_cv.shape[0],
                                           _ptr_table(params), d_item3.data_ptr(), _ptr_table(views), ctx.ws.data_ptr(),
-                                          ctx.ws.numel(), _stream()), "iisan_side_net_bwd")
+                                          ctx.ws.numel(), ctx.token, _stream()), "iisan_side_net_bwd")
         ctx.ws = None
         return (None, None, None) + ret
 
@@ -289,10 +290,11 @@ class InbatchCeFn(torch.autograd.Function):
         assert ids.numel() == bs * (S + 1) and score.shape[0] == bs * (S + 1) and prec.shape == (bs * S, E)
         loss = torch.empty((), dtype=torch.float32, device=score.device)
         ws = torch.empty(lib.iisan_inbatch_ce_ws_bytes(bs, S), dtype=torch.uint8, device=score.device)
+        token = C.c_uint64(0)
         _lib.check(lib.iisan_inbatch_ce_fwd(ids.data_ptr(), score.data_ptr(), prec.data_ptr(), log_mask.data_ptr(),
                                             pop_prob.data_ptr(), pop_prob.numel(), bs, S, E, loss.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            _stream()), "iisan_inbatch_ce_fwd")
-        ctx.ws = ws
+                                            C.byref(token), _stream()), "iisan_inbatch_ce_fwd")
+        ctx.ws, ctx.token = ws, token.value
         ctx.save_for_backward(ids, score, prec, log_mask, pop_prob)
         return loss
 
@@ -304,7 +306,7 @@ class InbatchCeFn(torch.autograd.Function):
         d_score, d_prec = torch.empty_like(score), torch.empty_like(prec)
         _lib.check(lib.iisan_inbatch_ce_bwd(ids.data_ptr(), score.data_ptr(), prec.data_ptr(), log_mask.data_ptr(),
                                             pop_prob.data_ptr(), bs, S, score.shape[1], 1.0, d_score.data_ptr(),
-                                            d_prec.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(), _stream()),
+                                            d_prec.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(), ctx.token, _stream()),
                    "iisan_inbatch_ce_bwd")
         ctx.ws = None
         # the upstream scalar stays on the device (no host sync): scale the two small gradient tensors

@@ -62,6 +62,7 @@ typedef struct {
     int32_t image, patch, channels;           /* 224, 16, 3                                                     */
     int32_t dtype16;
     float   eps;
+    int32_t full_blocks;                      /* dead-work policy, see below: 0 = default, 1 = every block on every token */
     const void*  patch_w;                     /* [D, C*P*P] 16-bit (Conv2d kernel flattened (c,py,px))          */
     const float* patch_b;                     /* [D]                                                            */
     const float* cls_token;                   /* [D]                                                            */
@@ -74,6 +75,7 @@ typedef struct {
     int32_t vocab, max_pos;
     int32_t dtype16;
     float   eps;
+    int32_t full_blocks;                      /* as in iisan_vit_weights                                        */
     const float* word_emb;                    /* [V, D] fp32 (gather only)                                      */
     const float* pos_emb;                     /* [max_pos, D]                                                   */
     const float* type_emb;                    /* [2, D] (row 0 used)                                            */
@@ -103,12 +105,11 @@ int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_t* text, in
                             const int32_t* tap_layers, int32_t n_taps, float* taps,
                             int64_t chunk_items, void* ws, size_t ws_bytes, void* stream);
 
-/* Dead-work policy of the two executors above.  By default (0) blocks deeper than the deepest tapped hidden state are
- * not run, and in the last live block attention / O / MLP / LayerNorm run for the CLS row of every item only (K and V
- * still for all tokens): the path consumes nothing but `hidden_states[i][:, 0]`, so the taps are the same values.
- * 1 = run every block on every token exactly like HF ViTModel / BertModel do (verification and ablation;
- * `bench.py --full-blocks`).  Process-wide. */
-void iisan_set_full_blocks(int32_t on);
+/* Dead-work policy of the two executors above (`full_blocks` of the weights struct — part of the call, not process state).
+ * 0 (default): blocks deeper than the deepest tapped hidden state are not run, and in the last live block attention / O /
+ * MLP / LayerNorm run for the CLS row of every item only (K and V still for all tokens): the path consumes nothing but
+ * `hidden_states[i][:, 0]`, so the taps are the same values.  1 = run every block on every token exactly like HF ViTModel /
+ * BertModel do (what `bench.py` measures: SURVEY 8d counts that work). */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Side network (IISANAdaptedMModel.forward, Code_Uncached/model/model.py:209-271; Cached model.py:300-349).
@@ -155,11 +156,14 @@ typedef struct {
 int32_t iisan_side_net_num_params(const iisan_side_cfg* cfg);
 size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M);        /* saved activations + scratch    */
 /* out: item3 fp32 [M, 3*emb] = cat[cv, text, mm] (the com_dense input, model.py:69) */
+/* `fwd_token` (out, host): what the backward call needs to know about THIS forward call — which kernel routes filled the
+ * workspace.  The caller carries it to iisan_side_net_bwd together with the workspace (the library keeps no per-call state:
+ * SURVEY 8b "stateless").  A backward call whose token does not match the routes it would take itself returns IISAN_EBADSHAPE. */
 int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
-                       const void* const* params, float* item3, void* ws, size_t ws_bytes, void* stream);
+                       const void* const* params, float* item3, void* ws, size_t ws_bytes, uint64_t* fwd_token, void* stream);
 int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_cv, const float* taps_text, int64_t M,
                        const void* const* params, const float* d_item3, void* const* grads,
-                       void* ws, size_t ws_bytes, void* stream);
+                       void* ws, size_t ws_bytes, uint64_t fwd_token, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Plain fp32 Linear (com_dense, Code_Uncached/model/model.py:36-37,69): y = x W^T + b ; bwd accumulates dW, db.
@@ -198,17 +202,21 @@ int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, const float* l
 size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S);
 int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                          const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t E, float* loss,
-                         void* ws, size_t ws_bytes, void* stream);
-/* d_loss: host scalar multiplier (upstream gradient).  d_score [M,E] and d_prec [T,E] are overwritten. */
+                         void* ws, size_t ws_bytes, uint64_t* fwd_token, void* stream);
+/* d_loss: host scalar multiplier (upstream gradient).  d_score [M,E] and d_prec [T,E] are overwritten.  `fwd_token`: the value
+ * the forward call on this workspace returned (it says whether that call left d_prec for d_loss = 1 in the workspace, which
+ * this call then only scales); 0 or a token of another call shape is IISAN_EBADSHAPE. */
 int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                          const float* pop_prob, int64_t bs, int32_t S, int32_t E, float d_loss,
-                         float* d_score, float* d_prec, void* ws, size_t ws_bytes, void* stream);
+                         float* d_score, float* d_prec, void* ws, size_t ws_bytes, uint64_t fwd_token, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Eval scoring (eval_model + metrics_topK, Code_Uncached/data_utils/metrics.py:59-67,198-207): for each user
  * the 1-based rank of `target` among items 1..item_num by score = prec . item_emb, history scored -inf, ties
  * towards the lower item id.  history: int32 [U, hist_stride] padded with 0.  ranks: int32 [U]; a target outside
  * 1..item_num is not dereferenced and yields rank -1, history ids outside that range are ignored.
+ * Limits (IISAN_EBADSHAPE otherwise): E == 64, hist_stride <= 256 (the history correction of a user lives in LDS), prec and
+ * item_emb 16-byte aligned.
  * ---------------------------------------------------------------------------------------------------------- */
 int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
                      const int32_t* history, int32_t hist_stride, const int32_t* target, int32_t* ranks,

@@ -63,14 +63,17 @@ def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
     assert err <= tol, f"gemm16 variant={variant} dt={dt} mode={mode} {shape}: max err {err:.3e} > {tol:.3e}"
 
 
-@pytest.mark.parametrize("shape", [(70000, 2304, 768, 0), (42240, 3072, 768, 1), (66000, 768, 3072, 0), (1300, 768, 256, 0)])
+@pytest.mark.parametrize("shape", [(70000, 2304, 768, 0), (42240, 3072, 768, 1), (66000, 768, 3072, 0), (1300, 768, 256, 0),
+                                   (40000, 768, 128, 0), (40000, 1536, 192, 1)])
 def test_gemm16_h256_race_screen_against_the_s256_kernel(lib, shape):
     """Race screen of the half-slot tile boundary (`csrc/gemm16_h256.hip`): its LDS-DMA pieces are issued from other slots than
     in `gemm16_s256.hip`, and a piece read before it has landed gives rare wrong tiles that come and go with memory load
     (cdna_hip_programming.md: place reads by the vmcnt / barrier count, never by clean runs).  Both kernels are deterministic
     and accumulate in the same order, so every run of either must give the same bits: 20 runs on fresh operands each, many
     tiles per workgroup (70,000 rows x 9 column tiles = 2,466 tiles on 256 CUs), a ragged last row tile, K = 768 and 3072,
-    the minimum K the kernel takes (four K-steps), plain and GELU epilogues."""
+    plain and GELU epilogues — and the SHORTEST tiles the kernel accepts: K = 128 (a tile is a first and a last K-step
+    with no middle step, every plan crosses the tile boundary) and K = 192 (one middle step); the panel tile walk of round 4 is
+    what the auto policy picks for the 2304- and 3072-column shapes here when M >= 32768."""
     M, N, K, mode = shape
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     out = {v: torch.empty(M, N, dtype=torch.float16, device="cuda") for v in (3, 4)}

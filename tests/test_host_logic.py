@@ -284,3 +284,22 @@ def test_bench_refuses_an_rccl_line_with_two_ranks_on_one_device():
         bench.check_one_device_per_rank("nccl", [r(0, "GPU-a"), r(0, "GPU-a")])
     with pytest.raises(SystemExit):
         bench.check_one_device_per_rank("nccl", [r(0, ""), r(0, "")])
+
+
+def test_h256_head_major_addressing_bound_is_independent_of_which0():
+    """`gemm16_h256_kernel` stores head-major QKV through 32-bit byte offsets into [item][head][3][S][64]; the
+    element-row index reaches rows * 3 * heads whatever `qkv_which0` is, so the applicability bound must too (it used 3 - which0:
+    row counts in [932k, 1.40M) passed with which0 = 1 and the offsets wrapped).  Pure host logic: no device is touched."""
+    from iisan_amd import _lib
+    lib = _lib.load()
+    QKV = 4                                       # EPI_QKVH16
+    heads, S = 12, 197
+    limit = (1 << 32) // (3 * heads * 128)        # rows beyond this cannot be addressed with 32 bits
+    for which0, N in ((0, 2304), (1, 1536)):
+        assert lib.iisan_gemm16_h256_applicable(QKV, 277376, N, 768, S, heads, which0) == 1          # the production shape
+        assert lib.iisan_gemm16_h256_applicable(QKV, 256 * (limit // 256 - 1), N, 768, S, heads, which0) == 1
+        for rows in (940_000, 1_200_000, 1_390_000, 256 * (limit // 256 + 1)):
+            assert lib.iisan_gemm16_h256_applicable(QKV, rows, N, 768, S, heads, which0) == 0, (which0, rows)
+    # the 16-bit row-major epilogues keep their own (leading-dimension) bound
+    assert lib.iisan_gemm16_h256_applicable(0, 1_390_000, 768, 768, 0, 0, 0) == 1
+    assert lib.iisan_gemm16_h256_applicable(0, 277376, 768, 64, 0, 0, 0) == 0                       # K / 64 < 2
