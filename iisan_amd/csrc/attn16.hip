@@ -33,8 +33,25 @@ constexpr float MASK_RAW = -0x1p126f;      // a power of two: MASK_RAW * c2 is e
 // One workgroup = one item x HPW consecutive heads, software-pipelined: while head h is being computed out of LDS,
 // the Q/K/V registers for head h+1 are already being filled from HBM (measured on the unpipelined version: the load
 // phase and the compute phase of a workgroup did not overlap at all and the kernel ran at 2.4 TB/s).
-template <typename T, int NT16>
-__global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::elem* __restrict__ qkv,
+// 16-key tail product of an odd tile count (ViT: 13 tiles): v_mfma_f32_16x16x16 with 4 contraction slots per lane (key base + 4 g + e)
+template <typename T> struct Mfma16k16;
+template <> struct Mfma16k16<F16> {
+    static __device__ __forceinline__ f4 run(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16k16<BF16> {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f4 run(b4 a, b4 b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+    }
+};
+
+// PF (prefetch): true (the product) — the next head's Q / K / V registers fill from HBM during this head's compute (92 registers held
+// across it: 227 VGPRs, two waves per SIMD, two workgroups per CU); false (round 4 experiment, kept behind iisan_set_attn_debug(32)) =
+// no register prefetch, 136 VGPRs and 54.6 KB of LDS so that THREE workgroups share a CU: one loads and stages while two compute.
+// Measured 4 % SLOWER (415-421 against 398-411 us per ViT layer): a third wave per SIMD does not make up for the load phase a
+// workgroup now waits out.
+template <typename T, int NT16, bool PF>
+__global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const typename T::elem* __restrict__ qkv,
                                                              const float* __restrict__ key_bias,
                                                              typename T::elem* __restrict__ ctx, int S, int heads, int hpw,
                                                              int dbg) {
@@ -44,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
     constexpr int SP = NT16 * 16;
     // V^T row stride (elements), see VT_LD below; (history: 264 = 132 dwords was chosen for a half-wave (16 d-rows x 2 key
     // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
-    constexpr int VT_LD = SP > 128 ? 260 : SP + 8;     // 130 dwords = 2 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (264 gave 2-way conflicts, PMC)
+    constexpr int VT_LD = SP > 128 ? 212 : SP + 8;     // 106 dwords = 10 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (round 3: 260 = 130 dwords, same property; 264 gave 2-way conflicts, PMC).  212 >= 208 + 4 keeps K + V^T + the key limits at 54,592 bytes: three workgroups per CU
     constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
     constexpr int KP = (SP + 31) / 32;                // K passes: 32 rows per pass (the last may be partial: NT16 odd)
     constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass
@@ -102,17 +119,17 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
             }
     };
 
-    load_head(h0);
+    if (PF) load_head(h0);
     for (int r = tid; r < SP; r += 256)
         sKB[r] = r >= S ? -INFINITY : ((key_bias && key_bias[(int64_t)item * S + r] < 0.f) ? MASK_RAW : INFINITY);   // per-key upper limit of the score
 
     // exp(s/8 - m) = exp2(acc * c2 - m2),  c2 = log2(e) / 8
-    if (NT16 % 2)              // keys SP .. SP+15 of the last P.V step: never loaded, multiplied by P = 0 — must be finite
-        for (int i = tid; i < 64 * 16; i += 256) sVt[(i >> 4) * VT_LD + SP + (i & 15)] = T::from_f32(0.f);
+    // (an odd tile count ends with a 16-key product of its own, Mfma16k16: no zero-filled half step, no LDS for it)
     const float c2 = 0.18033688011112042f;
 #pragma unroll 1
     for (int hi = 0; hi < hpw; ++hi) {
         const int h = h0 + hi;
+        if (!PF) load_head(h);                // (the other workgroups of the CU compute meanwhile)
         if (hi > 0) __syncthreads();          // every wave is done reading the previous head's K / V^T
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) qf[i][kk] = qnext[i][kk];
         __syncthreads();
-        if (hi + 1 < hpw) load_head(h + 1);   // in flight during this head's compute
+        if (PF && hi + 1 < hpw) load_head(h + 1);   // in flight during this head's compute
 
 #pragma unroll
         for (int i = 0; i < MAXQB; ++i) {
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
                 };
                 V8 vc[4];
                 vload(0, vc);
-                constexpr int NPV = (NT16 + 1) / 2;            // 32-key steps of P.V; with NT16 odd the last one has a zero half
+                constexpr int NPV = NT16 / 2;                  // 32-key steps of P.V (an odd tile count: + one 16-key step below)
 #pragma unroll
                 for (int kb = 0; kb < NPV; ++kb) {
                     V8 vn[4];
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         pf[e] = T::from_f32(sc[2 * kb][e]);
-                        pf[4 + e] = 2 * kb + 1 < NT16 ? T::from_f32(sc[2 * kb + 1][e]) : T::from_f32(0.f);
+                        pf[4 + e] = T::from_f32(sc[2 * kb + 1][e]);
                     }
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) o[dt] = T::mfma(vc[dt], pf, o[dt]);
@@ -247,6 +264,14 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const typename T::e
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) vc[dt] = vn[dt];
                     }
+                }
+                if constexpr (NT16 % 2 == 1) {                 // keys SP-16 .. SP-1
+                    V4 pt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pt[e] = T::from_f32(sc[NT16 - 1][e]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        o[dt] = Mfma16k16<T>::run(*(const V4*)(sVt + (dt * 16 + j) * VT_LD + (SP - 16) + g * 4), pt, o[dt]);
                 }
             }
             // A lane holds 4 consecutive head dims (8 B) of its query per 16-dim tile; lanes 16 apart (g, g+1) hold the
@@ -406,13 +431,19 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     // heads measured 420 / 421 / 428 / 437 us per ViT layer in isolation and 68.55 / 68.58 / 68.78 ms per step
     const int hpw = heads % 2 == 0 ? 2 : 1;
     dim3 grid((unsigned)(items * (heads / hpw))), block(256);
+    // g_attn_dbg bit 5 (32): the three-workgroups-per-CU kernel without register prefetch (A/B knob, tools/attn_pf_ab.py: same-process
+    // rounds on the ViT shape 415-421 us against 398-411 us for the prefetching kernel with two workgroups per CU — the default; both
+    // carry round 4's 16-key tail product: bit-identical outputs, -3..6 % against round 3's 424 us)
 #define IISAN_ATTN_CASE(NT)                                                                                        \
-    hipLaunchKernelGGL((attention16_kernel<T, NT>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg)
-    if (S <= 32) IISAN_ATTN_CASE(2);
-    else if (S <= 64) IISAN_ATTN_CASE(4);
-    else if (S <= 128) IISAN_ATTN_CASE(8);
-    else if (S <= 208) IISAN_ATTN_CASE(13);   // ViT: 197 tokens = 13 tiles of 16 keys (a 14th would be pure padding)
-    else if (S <= 224) IISAN_ATTN_CASE(14);
+    if (!(g_attn_dbg & 32))                                                                                        \
+        hipLaunchKernelGGL((attention16_kernel<T, NT, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31); \
+    else                                                                                                           \
+        hipLaunchKernelGGL((attention16_kernel<T, NT, false>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
+    if (S <= 32) { IISAN_ATTN_CASE(2); }
+    else if (S <= 64) { IISAN_ATTN_CASE(4); }
+    else if (S <= 128) { IISAN_ATTN_CASE(8); }
+    else if (S <= 208) { IISAN_ATTN_CASE(13); }   // ViT: 197 tokens = 13 tiles of 16 keys (a 14th would be pure padding)
+    else if (S <= 224) { IISAN_ATTN_CASE(14); }
     else {
         iisan_set_error("attention16: sequence length %d > 224 not supported", S);
         return IISAN_EBADSHAPE;
