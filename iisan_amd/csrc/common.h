@@ -293,6 +293,10 @@ struct Gemm32Prob {
     uint32_t* amax_a; uint32_t* amax_b;
     int32_t amax_a_ready, amax_b_ready;
     uint32_t* x3_zeroed;   // gemm_x3 only: 12 words the caller has zeroed for this product alone (private amax, 1/scale, lo flags); null = zeroed here
+    // weight-gradient products (G32_TA | G32_TB | G32_ACCUM, A stored [K, M]): colsum_a[m] += sum_k A[k][m] — the bias gradient that
+    // belongs to the same dY.  gemm32_dw_kernel sums the A tiles it stages anyway (round 3 re-read dY in a colsum launch of its
+    // own: 0.94 GB and 20 launches per Cached step); every other route falls back to that launch.  null = not wanted.
+    float* colsum_a;
 };
 // fusion-fed down projection of the separate SANB launches (gemm32.hip: gemm32_n64f_kernel):  F = fuse(a, b, prev) is formed in the
 // registers that feed the product, written out once, and  U = F·W^T + bias,  A = act(U)  leave together

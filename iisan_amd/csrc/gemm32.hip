@@ -405,6 +405,9 @@ __global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
         for (int f = 0; f < 4; ++f) acc[e][f] = (f4){0.f, 0.f, 0.f, 0.f};
     const int sw = (tid >> 4) * 64 + (tid & 15) * 4;                // staging write offset (+ 16 * 64 q)
     const int rd = (16 * wave + kq) * 64 + 4 * i16;                 // fragment read offset (+ 4 * 64 s)
+    // column sums of the A operand (the bias gradient of the same dY): the workgroups of column tile 0 add up the pieces they stage
+    const bool do_cs = p.colsum_a != nullptr && tile_n == 0;
+    f4 csum = {0.f, 0.f, 0.f, 0.f};
     auto tile = [&](int64_t t, int slot) {
         float* bufA = sm[t & 1][0];
         float* bufB = sm[t & 1][1];
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
         for (int q = 0; q < 4; ++q) {
             *(f4*)(bufA + sw + 16 * 64 * q) = st[slot][q];
             *(f4*)(bufB + sw + 16 * 64 * q) = st[slot][4 + q];
+            if (do_cs) csum += st[slot][q];
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -456,6 +460,18 @@ __global__ __launch_bounds__(256, 2) void gemm32_dw_kernel(Gemm32Batch batch) {
         const int o = (id >> 4) * 64 + (id & 15) * 4;
         const f4 v = (*(const f4*)(all + o) + *(const f4*)(all + 4096 + o)) + (*(const f4*)(all + 8192 + o) + *(const f4*)(all + 12288 + o));
         *(f4*)(Cp + (m0 + (id >> 4)) * p.ldc + n0 + (id & 15) * 4) = v;
+    }
+    if (do_cs) {            // sixteen threads hold partial sums of the same four columns: through LDS, fixed order, behind the C partial
+        __syncthreads();
+        float* cs = &sm[0][0][0];
+        *(f4*)(cs + (tid >> 4) * 64 + (tid & 15) * 4) = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += cs[r * 64 + tid];
+            Cp[p.M * p.N + m0 + tid] = v;
+        }
     }
 }
 
@@ -783,12 +799,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
 // C = epilogue(sum_y P[y] + bias) (+ resid): the split-K partial products of up to 4 problems, fixed summation order
 // ns[z] = the K-splits of problem z that own a non-empty K range: only those wrote a partial (a shorter K than its launch
 // mates' leaves the rest of the scratch slots untouched — they are never read, so the scratch needs no zeroing)
-struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; int32_t ns[4]; };
+struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; int32_t ns[4]; float* cs[4]; };     // cs: colsum_a of problem z (its partials follow the C partial of every split)
 __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int ks_launch, int epi) {
     const Gemm32Prob& p = rb.p[blockIdx.z];
     const int ks = ks_launch < rb.ns[blockIdx.z] ? ks_launch : rb.ns[blockIdx.z];
     const float* P = rb.P[blockIdx.z];
     const int64_t stride = rb.stride[blockIdx.z], total = p.M * p.N;
+    if (rb.cs[blockIdx.z] && blockIdx.x == 0) {         // column sums of the A operand: M values per split, fixed order
+        for (int64_t m = threadIdx.x; m < p.M; m += blockDim.x) {
+            float v = 0.f;
+            for (int y = 0; y < ks; ++y) v += P[(int64_t)y * stride + total + m];
+            rb.cs[blockIdx.z][m] += v;
+        }
+    }
     if (epi == 0 && !p.bias && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.resid || (p.ldr & 3) == 0)) {
         // plain sum (+ old C): the weight-gradient reductions.  16-byte accesses, eight partials in flight per thread; the
         // summation order is fixed (y ascending within each of the eight lanes of the unroll, lanes combined in order)
@@ -1004,6 +1027,8 @@ static int launch_gemm32_k64_gate_impl(const Gemm32Prob* probs, const K64Gate* g
     return IISAN_OK;
 }
 
+int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
+                  int nprob, hipStream_t s);
 static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
     IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
     Gemm32Batch b{};
@@ -1129,14 +1154,16 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
             const int64_t ktiles = ceil_div(min_k, (int64_t)TK), per = ceil_div(ktiles, (int64_t)splitk);
             splitk = (int)ceil_div(ktiles, per);
         }
+        // (+ M floats behind every C partial for the A operand's column sums, where gemm32_dw_kernel computes them)
+        auto cs_floats = [&](const Gemm32Prob& q) { return (dw_ok && q.colsum_a) ? q.M : 0; };
         int64_t need = 0;
-        for (int i = 0; i < nprob; ++i) need += (int64_t)splitk * (int64_t)align_up((size_t)(probs[i].M * probs[i].N), 64);
+        for (int i = 0; i < nprob; ++i) need += (int64_t)splitk * (int64_t)align_up((size_t)(probs[i].M * probs[i].N + cs_floats(probs[i])), 64);
         if ((size_t)need <= g_scratch_floats) {
             int64_t off = 0;
             for (int i = 0; i < nprob; ++i) {
                 Gemm32Prob& q = b.p[i];
                 q.C = g_scratch + off; q.ldc = q.N; q.bias = nullptr; q.resid = nullptr; q.act_src = nullptr;
-                q.ksplit_stride = (int64_t)align_up((size_t)(q.M * q.N), 64);
+                q.ksplit_stride = (int64_t)align_up((size_t)(q.M * q.N + cs_floats(q)), 64);
                 off += splitk * q.ksplit_stride;
                 orig.p[i].resid = orig.p[i].C;          // the reducer adds the old C:  C = sum of partials + C
                 orig.p[i].ldr = orig.p[i].ldc;
@@ -1156,10 +1183,12 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
     }
     const int epi = via_scratch ? 0 : (flags & ~(G32_TA | G32_TB | G32_ACCUM));
     int rc;
+    bool cs_folded = false;          // the A operand's column sums came out of the product kernel
     if (dw_ok && via_scratch && structural == (G32_TA | G32_TB)) {
         hipLaunchKernelGGL(gemm32_dw_kernel, grid, dim3(256), 0, s, b);
         IISAN_LAUNCH_OK();
         rc = IISAN_OK;
+        cs_folded = true;
     } else
     switch (structural) {
 #define G32_CASE(F) case (F): rc = launch_flags<(F)>(b, grid, TM, epi, fast, min_k >= 4096, s); break
@@ -1174,6 +1203,13 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
 #undef G32_CASE
         default: iisan_set_error("gemm32: bad flags 0x%x", flags); return IISAN_EBADSHAPE;
     }
+    if (rc == IISAN_OK && !cs_folded && (flags & G32_TA)) {          // every other route: the column sums as a launch of their own
+        const float* X[4]; float* O[4]; int64_t Ms[4]; int32_t Ns[4], lds[4];
+        int n = 0;
+        for (int i = 0; i < nprob; ++i)
+            if (probs[i].colsum_a) { X[n] = probs[i].A; O[n] = probs[i].colsum_a; Ms[n] = probs[i].K; Ns[n] = (int32_t)probs[i].M; lds[n] = probs[i].lda; ++n; }
+        if (n) IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, n, s));
+    }
     if (rc != IISAN_OK || !via_scratch) return rc;
     ReduceBatch rb{};
     int64_t max_mn = 0;
@@ -1181,6 +1217,7 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
         rb.p[i] = orig.p[i];
         rb.P[i] = b.p[i].C;
         rb.stride[i] = b.p[i].ksplit_stride;
+        rb.cs[i] = cs_folded ? orig.p[i].colsum_a : nullptr;
         {   // the kernel gives split y the K-tiles [y, y+1) * ceil(ktiles / splits)
             const int64_t ktiles = ceil_div(orig.p[i].K, (int64_t)TK), per = ceil_div(ktiles, (int64_t)splitk);
             rb.ns[i] = (int32_t)ceil_div(ktiles, per);

@@ -596,15 +596,18 @@ struct ReduceTab { float* g[100]; int32_t off[100]; int32_t cnt[100]; int32_t n;
 __global__ __launch_bounds__(256) void sasrec_reduce_kernel(const float* __restrict__ slab, int64_t stride, int nwg, ReduceTab t) {
     const int i = blockIdx.y;
     if (i >= t.n) return;
+    // one element per thread, eight independent partial sums (a fixed tree: reproducible); the 16-element version with 16 workgroups
+    // per tensor took 84 us at bs = 1024 (256 slabs x 100 K floats = 103 MB at 1.2 TB/s)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < t.cnt[i]; e += gridDim.x * 256) {
         const float* p = slab + t.off[i] + e;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int w = 0;
-        for (; w + 4 <= nwg; w += 4) {
-            s0 += p[(int64_t)w * stride]; s1 += p[(int64_t)(w + 1) * stride]; s2 += p[(int64_t)(w + 2) * stride]; s3 += p[(int64_t)(w + 3) * stride];
+        for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc[u] += p[(int64_t)(w + u) * stride];
         }
-        for (; w < nwg; ++w) s0 += p[(int64_t)w * stride];
-        t.g[i][e] += (s0 + s1) + (s2 + s3);
+        for (; w < nwg; ++w) sacc[0] += p[(int64_t)w * stride];
+        t.g[i][e] += ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
     }
 }
 
@@ -698,7 +701,7 @@ int launch_sasrec_fused_bwd(const iisan_sasrec_cfg* cfg, const float* log_mask, 
         default: iisan_set_error("sasrec_fused: head width %d not instantiated", FE / cfg->heads); return IISAN_EBADSHAPE;
     }
     IISAN_LAUNCH_OK();
-    hipLaunchKernelGGL(sasrec_reduce_kernel, dim3(16, tab.n), dim3(256), 0, s, slab, a.slab_stride, nwg, tab);
+    hipLaunchKernelGGL(sasrec_reduce_kernel, dim3(64, tab.n), dim3(256), 0, s, slab, a.slab_stride, nwg, tab);      // 64 x 256 threads: one element each of the largest tensors
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

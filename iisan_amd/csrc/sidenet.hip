@@ -647,17 +647,15 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
         for (int a = 0; a < na; ++a) {
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);
+            pr[a].colsum_a = G(p.wd(z, k) + 3);                                   // dbu += column sums of dO: out of the same product
         }
         IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWu += dO^T · A
-        for (int a = 0; a < na; ++a) { const int z = sm.z[a], k = sm.k[a]; cs_x[a] = b.dO[z]; cs_o[a] = G(p.wd(z, k) + 3); cs_n[a] = p.D[z]; cs_ld[a] = p.D[z]; }
-        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, na, s));
         for (int a = 0; a < na; ++a) {
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.dU[z], r, b.F[k][z], p.D[z], nullptr, G(p.wd(z, k)), p.D[z], r, p.D[z], M);
+            pr[a].colsum_a = G(p.wd(z, k) + 1);                                   // dbd += column sums of dU
         }
         IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWd += dU^T · F
-        for (int a = 0; a < na; ++a) { const int z = sm.z[a], k = sm.k[a]; cs_x[a] = b.dU[z]; cs_o[a] = G(p.wd(z, k) + 1); cs_n[a] = r; cs_ld[a] = r; }
-        IISAN_TRY(launch_colsum(cs_x, cs_o, cs_m, cs_n, cs_ld, na, s));
         for (int a = 0; a < na; ++a) {
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.dU[z], r, c.W(p.wd(z, k)), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], r, b.dO[z], p.D[z]);
