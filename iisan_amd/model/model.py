@@ -115,10 +115,12 @@ class IISANAdaptedMModel(_SideNetBase):
             taps_cv = self.cv_encoder.forward_taps(sample_items_images.index_select(0, first), need).index_select(0, inverse)
             taps_text = self.bert_encoder.forward_taps(sample_items_text.index_select(0, first), need).index_select(0, inverse)
         else:
-            if getattr(self, "overlap_towers", True) and sample_items_images.is_cuda:
-                # default since round 4 (`overlap_towers = False` to opt out): the text tower on a second HIP stream, so its
-                # small kernels fill the tails of the image tower's persistent GEMMs (same kernels, same results; -2.4 % step
-                # time: 66.6 -> 65.0 ms at bs = 128)
+            if getattr(self, "overlap_towers", False) and sample_items_images.is_cuda:
+                # opt-in: the text tower on a second HIP stream, so its kernels fill the tails of the image tower's persistent
+                # GEMMs (same kernels, same results; -1.6 % step time: 66.7 -> 65.6 ms at bs = 128, round 4).  Not the default:
+                # the towers' kernels then share the CUs and every per-kernel duration (HIP events, rocprofv3) is inflated by
+                # the sharing — a ViT GEMM's trace duration grows from 0.39 to 0.75 ms — so the step stops being accountable
+                # kernel by kernel (profiles/r4_overlap_by_stream.md)
                 cur = torch.cuda.current_stream()
                 if getattr(self, "_side_stream", None) is None:
                     self._side_stream = torch.cuda.Stream()

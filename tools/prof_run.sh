@@ -9,6 +9,8 @@ rm -rf $out && mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out -o bench -- python3 bench.py "$@" > $out/bench.log 2>&1
 python3 tools/rocpd_summary.py $(find $out -name "*.db" | head -1) > $out/summary.md 2>/dev/null
 python3 tools/rocpd_seq.py $(find $out -name "*.db" | head -1) > $out/sequence.txt 2>/dev/null
+python3 tools/rocpd_summary.py $(find $out -name "*.db" | head -1) --schema > $out/schema.txt 2>&1
+python3 tools/rocpd_summary.py $(find $out -name "*.db" | head -1) --by-stream > $out/by_stream.md 2>&1
 find $out -name "*.db" -delete
 head -$rows $out/summary.md | cut -c1-200
 grep "^{" $out/bench.log | tail -1 | cut -c1-400
