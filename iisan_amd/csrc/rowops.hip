@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float* x, const
 // fp32 arithmetic everywhere else, +9e-5 relative on every tap (all rows in fp16: 6.8e-4) against the 8.8e-4 the 16-bit operands
 // cost and the 1.5e-3 budget.  Bytes per token row and ViT block: LN1 10 + LN2 6 = 16 instead of 14 + 8 = 22 (BERT: 8
 // instead of 12 per LayerNorm) in kernels that run at the HBM rate.
-// One wave per token row; a workgroup = 4 consecutive tokens of ONE item (the CLS test is wave-uniform and costs no division
-// per lane).  V: which operands exist (compile time, as above).
+// HALF a wave per token row (32 lanes x three 8-element pieces), a workgroup = 8 consecutive tokens of ONE item (the CLS test costs no
+// division per lane): every access of the fp16 stream, the 16-bit deltas and the 16-bit image is a full 16-byte lane access.  (The
+// first version gave a row to a whole wave — 12 elements per lane as three 8-byte pieces: 4.3 TB/s on LN1 where the fp32 kernel's
+// 16-byte accesses reach 6.7; MI355X_MICROARCH.md: 8-byte accesses run at 0.54-0.70 x the 16-byte rate.)  V: which operands exist.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __restrict__ x32, _Float16* x16, float* xc,
                                                                  const typename T::elem* __restrict__ delta,
@@ -100,56 +102,61 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
                                                                  typename T::elem* __restrict__ out16, int64_t items, int Ttok) {
     constexpr bool D1 = (V & MX_D1) != 0, D2 = (V & MX_D2) != 0, LN = (V & MX_LN) != 0, RESV = (V & MX_RESV) != 0,
                    RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0;
-    typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    typedef typename T::v8 V8;
+    const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;          // 8 half-waves per workgroup
     int64_t item;
     int tok;
     if (CLSONLY) {
-        item = (int64_t)blockIdx.x * 4 + wv; tok = 0;
+        item = (int64_t)blockIdx.x * 8 + half; tok = 0;
         if (item >= items) return;
     } else {
-        const int bpi = (Ttok + 3) >> 2;
+        const int bpi = (Ttok + 7) >> 3;
         item = blockIdx.x / bpi;
-        tok = (int)(blockIdx.x - item * bpi) * 4 + wv;
+        tok = (int)(blockIdx.x - item * bpi) * 8 + half;
         if (tok >= Ttok) return;
     }
     const int64_t row = item * Ttok + tok;
-    const bool cls = tok == 0;
-    typename T::v4 d1[3], d2[3];
+    const bool cls = tok == 0;                                            // uniform within the half-wave
+    V8 d1[3], d2[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (D1) d1[i] = __builtin_nontemporal_load((const typename T::v4*)(delta + row * 768 + i * 256 + lane * 4));
-        if (D2) d2[i] = __builtin_nontemporal_load((const typename T::v4*)(delta2 + row * 768 + i * 256 + lane * 4));
+        if (D1) d1[i] = __builtin_nontemporal_load((const V8*)(delta + row * 768 + i * 256 + lane * 8));
+        if (D2) d2[i] = __builtin_nontemporal_load((const V8*)(delta2 + row * 768 + i * 256 + lane * 8));
     }
-    f4 v[3];
+    float v[3][8];
     if (cls) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) v[i] = *(const f4*)(xc + item * 768 + i * 256 + lane * 4);
+        for (int i = 0; i < 3; ++i) {
+            const f4 a = *(const f4*)(xc + item * 768 + i * 256 + lane * 8), c = *(const f4*)(xc + item * 768 + i * 256 + lane * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = c[e]; }
+        }
     } else if (SRC32) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) v[i] = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 4));
-    } else {
-        hv4 xh[3];
+        for (int i = 0; i < 3; ++i) {
+            const f4 a = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 8));
+            const f4 c = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 8 + 4));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xh[i] = __builtin_nontemporal_load((const hv4*)(x16 + row * 768 + i * 256 + lane * 4));
+            for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = c[e]; }
+        }
+    } else {
+        h8 xh[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xh[i] = __builtin_nontemporal_load((const h8*)(x16 + row * 768 + i * 256 + lane * 8));
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = (float)xh[i][e];
+            for (int e = 0; e < 8; ++e) v[i][e] = (float)xh[i][e];
     }
-    f4 gg[3], bb[3];
-    if (LN) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { gg[i] = *(const f4*)(g + i * 256 + lane * 4); bb[i] = *(const f4*)(b + i * 256 + lane * 4); }
-    }
-    auto put_resid = [&](int i, const f4& val) {
+    auto put_resid = [&](int i, const float (&val)[8]) {
         if (cls) {
-            *(f4*)(xc + item * 768 + i * 256 + lane * 4) = val;
+            *(f4*)(xc + item * 768 + i * 256 + lane * 8) = (f4){val[0], val[1], val[2], val[3]};
+            *(f4*)(xc + item * 768 + i * 256 + lane * 8 + 4) = (f4){val[4], val[5], val[6], val[7]};
         } else {
-            hv4 o;
+            h8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)val[e];
-            __builtin_nontemporal_store(o, (hv4*)(x16 + row * 768 + i * 256 + lane * 4));
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)val[e];
+            __builtin_nontemporal_store(o, (h8*)(x16 + row * 768 + i * 256 + lane * 8));
         }
     };
     float s = 0.f;
@@ -157,37 +164,47 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
     for (int i = 0; i < 3; ++i) {
         if (D1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d1[i][e]);
+            for (int e = 0; e < 8; ++e) v[i][e] += T::to_f32(d1[i][e]);
         }
-        if (D2) {
+        if (D2) {       // added AFTER delta, in fp32: (x + delta) + delta2
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(d2[i][e]);
+            for (int e = 0; e < 8; ++e) v[i][e] += T::to_f32(d2[i][e]);
         }
         if (RESV) put_resid(i, v[i]);
-        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
     }
     if (!LN) return;
-    const float mean = wave_sum(s) * (1.0f / 768.0f);
+    auto sum32 = [](float t) {          // over the 32 lanes of the half-wave
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    const float mean = sum32(s) * (1.0f / 768.0f);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const float d = v[i][e] - mean;
             q += d * d;
         }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 768.0f) + eps);
+    const float rstd = rsqrtf(sum32(q) * (1.0f / 768.0f) + eps);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int c = i * 256 + lane * 4;
-        f4 y;
+        const int c = i * 256 + lane * 8;
+        const f4 g0 = *(const f4*)(g + c), g1 = *(const f4*)(g + c + 4), b0 = *(const f4*)(b + c), b1 = *(const f4*)(b + c + 4);
+        float y[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+        for (int e = 0; e < 4; ++e) {
+            y[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+            y[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+        }
         if (RESY) put_resid(i, y);
-        typename T::v4 o;
+        V8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = T::from_f32(y[e]);
-        *(typename T::v4*)(out16 + row * 768 + c) = o;
+        for (int e = 0; e < 8; ++e) o[e] = T::from_f32(y[e]);
+        *(V8*)(out16 + row * 768 + c) = o;
     }
 }
 
@@ -361,7 +378,7 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
 int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
                               const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s) {
     if (items <= 0) return IISAN_OK;
-    const int64_t blocks = (V & MX_CLSONLY) ? ceil_div(items, 4) : items * ((Ttok + 3) / 4);
+    const int64_t blocks = (V & MX_CLSONLY) ? ceil_div(items, 8) : items * ((Ttok + 7) / 8);
     IISAN_CHECK_SHAPE(blocks < (1ll << 31), "layernorm768_mixed: grid too large");
     dim3 grid((unsigned)blocks), block(256);
 #define MX_CASE(VV)                                                                                                            \

@@ -88,9 +88,11 @@ def test_fp32_residual_stream_and_mixed_stream_both_match_the_golden(lib):
             assert _rel(tc[:, l], ref_c[:, l]) < tol, (r32, fb, l, _rel(tc[:, l], ref_c[:, l]))
             assert _rel(tt[:, l], ref_t[:, l]) < tol, (r32, fb, l, _rel(tt[:, l], ref_t[:, l]))
     for fb in (0, 1):
-        # taps 0 and 1 never see a rounded stream row (block 0 reads the fp32 embeddings): bit-equal
-        assert torch.equal(out[(0, fb)][0][:, :2], out[(1, fb)][0][:, :2]) and torch.equal(out[(0, fb)][1][:, :2], out[(1, fb)][1][:, :2])
-        for l in range(2, 13):
+        # tap 0 is the embedding; tap 1 never sees a rounded stream row (block 0 reads the fp32 embeddings) — the two LayerNorm
+        # kernels only sum a row in different orders, which moves single fp16 roundings of the LayerNorm image
+        assert torch.equal(out[(0, fb)][0][:, 0], out[(1, fb)][0][:, 0]) and torch.equal(out[(0, fb)][1][:, 0], out[(1, fb)][1][:, 0])
+        # (measured 3.0e-4 on ViT tap 1: one block of decorrelated fp16 roundings, as between any two correct executions)
+        for l in range(1, 13):
             assert _rel(out[(0, fb)][0][:, l], out[(1, fb)][0][:, l]) < 1e-3 and _rel(out[(0, fb)][1][:, l], out[(1, fb)][1][:, l]) < 1e-3
 
 
