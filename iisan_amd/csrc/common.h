@@ -252,7 +252,9 @@ struct Gemm16Args {
     int64_t split_stride;   // EPI_F32 split-K: K-split y writes its partial product to out + y*split_stride (bias / resid: reducer)
     const int32_t* skip_last_third;   // EPI_F32: device flag; when it reads 0 the last third of K is all zeros and is not multiplied
 };
-enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5 };
+enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5, EPI_PATCH16 = 6 };
+// EPI_PATCH16: 16-bit output, patch row m of image m / P -> token row m + m / P + 1 (bias added; the position embedding is added by
+// the LayerNorm kernel that reads the rows — rowops.hip, MX_POSROW)
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
 // slice the attention kernel streams is then one contiguous block instead of 128-byte pieces at a 4.6 KB stride.
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
@@ -266,7 +268,9 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
                              const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 // mixed-precision residual stream (rowops.hip: layernorm768_mixed_kernel): CLS rows fp32 in `xc` [items, 768], every other token
 // row fp16 in `x16` [items * Ttok, 768]; V = which operands exist
-enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64 };
+enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64, MX_POSROW = 128 };
+// MX_POSROW (with MX_SRC32 | MX_D1): the fp32 source is a [Ttok, 768] table indexed by the TOKEN (the position embedding) and the delta is
+// the patch embedding of that token; CLS rows take neither (their stream holds cls + pos[0] already)
 int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
                               const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,

@@ -159,8 +159,11 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         const void* img0 = img_u8 ? (const void*)((const uint8_t*)images + m0 * img_elems)
                                   : (const void*)((const float*)images + m0 * img_elems);
         IISAN_TRY(launch_vit_im2col(dt, img0, img_u8, b.F1, mc, w->channels, w->image, w->patch, s));
-        IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));
         const bool mixed = !g_resid32;
+        // patch embedding: resid32 = fp32 token rows with the position embedding added (p256 / v1 kernels); mixed = 16-bit rows on the
+        // production GEMM (gemm16_h256, 0.40 against 0.59 ms at bs = 128), the position table is added by block 0's LayerNorm
+        if (mixed) IISAN_TRY(gemm(dt, EPI_PATCH16, b.F1, pd, w->patch_w, w->patch_b, b.D16b, D, nullptr, mc * P, s, nullptr, P));
+        else IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));
         // CLS rows: cls + pos[0] — into the fp32 stream (token-major) or into the compact fp32 CLS stream
         IISAN_TRY(launch_vit_cls_rows(mixed ? b.Xc : b.X, w->cls_token, w->pos_emb, mc, mixed ? 1 : T, D, s));
         // the tapped rows of the current hidden state: CLS rows of X (stride T) or the compact CLS stream itself
@@ -183,8 +186,8 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
             // x += pending deltas of block l-1 ; h = LN1(x)            -> the stream is hidden state l
             if (!mixed)
                 IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
-            else if (l == 0)     // fp32 embeddings -> fp16 stream of the patch rows (the CLS rows are in Xc already) + LN image
-                IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_RESV | MX_LN, b.X, b.X16, b.Xc, nullptr, nullptr, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
+            else if (l == 0)     // position table + 16-bit patch embedding -> fp16 stream of the patch rows (the CLS rows are in Xc already) + LN image
+                IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_POSROW | MX_D1 | MX_RESV | MX_LN, w->pos_emb, b.X16, b.Xc, b.D16b, nullptr, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
             else
                 IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_D2 | MX_RESV | MX_LN, nullptr, b.X16, b.Xc, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
             pend_o = pend_f = nullptr;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                     v[4 + r] += b1[r];
                 }
             }
-            if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16 || EPI == EPI_QKVH16) {
+            if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16 || EPI == EPI_QKVH16 || EPI == EPI_PATCH16) {
                 V8 o;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) o[r] = T::from_f32(EPI == EPI_GELU16 ? gelu_erf_fast(v[r]) : v[r]);
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                     const int tok = (int)(m - item * p.qkv_S);
                     const int wq_ = n / Dm, hd = (n - wq_ * Dm) >> 6, d = n & 63, which = wq_ + p.qkv_which0;
                     *(V8*)((typename T::elem*)p.out + (((item * p.qkv_heads + hd) * 3 + which) * p.qkv_S + tok) * 64 + d) = o;
+                } else if constexpr (EPI == EPI_PATCH16) {
+                    *(V8*)((typename T::elem*)p.out + (m + m / p.patch_P + 1) * p.ldo + n) = o;
                 } else {
                     *(V8*)((typename T::elem*)p.out + m * p.ldo + n) = o;
                 }
@@ -211,6 +213,7 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
         case EPI_RESID32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_RESID32>), grid, block, 0, s, a); break;
         case EPI_PATCH32: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH32>), grid, block, 0, s, a); break;
         case EPI_QKVH16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_QKVH16>), grid, block, 0, s, a); break;
+        case EPI_PATCH16: hipLaunchKernelGGL((gemm16_kernel<T, EPI_PATCH16>), grid, block, 0, s, a); break;
         default: iisan_set_error("gemm16: bad epilogue mode %d", mode); return IISAN_EBADSHAPE;
     }
     IISAN_LAUNCH_OK();
@@ -274,6 +277,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.N % BN == 0 && a.K % BK == 0, "gemm16: N (%d) must be a multiple of %d and K (%d) of %d", a.N, BN, a.K, BK);
     IISAN_CHECK_SHAPE(ceil_div(a.M, BM) * (a.N / BN) < (1ll << 31), "gemm16: grid too large");
     IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
+    IISAN_CHECK_SHAPE(mode != EPI_PATCH16 || a.patch_P > 0, "gemm16: patch mode needs P");
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
     IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.qkv_which0 >= 0 && a.qkv_which0 <= 2 && a.N == (3 - a.qkv_which0) * 64 * a.qkv_heads),
                       "gemm16: head-major QKV mode needs S, heads and N == 3*64*heads");
@@ -302,7 +306,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
         b.debug = g_variant >> 8;
         if (g_desync && (mode == EPI_QKVH16 || mode == EPI_GELU16) && a.K <= 1024) b.debug |= 4;
         rc = launch_gemm16_s256(dtype16, mode, b, s);
-    } else if (big && gemm16_p256_applicable(a)) {
+    } else if (big && mode != EPI_PATCH16 && gemm16_p256_applicable(a)) {       // (the 16-bit patch epilogue: gemm16_h256 or the 128x128 kernel)
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
         rc = launch_gemm16_p256(dtype16, mode, b, s);

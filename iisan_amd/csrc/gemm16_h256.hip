@@ -424,7 +424,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     const int mrow = row0 + mi * 32;                       // (wave-uniform) first row of the block
                     char* op;
                     bool ok = true;
-                    if constexpr (EPI == EPI_QKVH16) {
+                    if constexpr (EPI == EPI_PATCH16) {
+                        // patch row m of image m / P -> token row m + m / P + 1 (one v_mul_hi by the host's reciprocal of P)
+                        const uint32_t m = (uint32_t)(mrow + frow);
+                        const uint32_t R = m + __umulhi(m, qkv_magic) + 1u;
+                        op = (char*)p.out + ((uint32_t)(R * (uint32_t)(p.ldo * 2)) + (uint32_t)((col0 + ni * 32) * 2) + (uint32_t)(fh * 32));
+                        if (!FULL) ok = (int64_t)m < p.M;
+                    } else if constexpr (EPI == EPI_QKVH16) {
                         const uint32_t m = (uint32_t)(mrow + frow);
                         const uint32_t item = __umulhi(m, qkv_magic);        // m / S (exact: m * S < 2^32, checked by the launcher)
                         const uint32_t R = item * qk_istride + m + qk_rowadd;
@@ -615,7 +621,8 @@ int launch_epi(const Gemm16Args& a, hipStream_t s) {
     int grid = (int)(ntiles < cus ? ntiles : cus);
     grid = (grid + 7) / 8 * 8;
     // EPI_QKVH16: item = row / S as one v_mul_hi_u32 by floor(2^32 / S) + 1 — exact while row * S < 2^32 (gemm16_h256_applicable)
-    const uint32_t magic = a.qkv_S > 0 ? (uint32_t)((1ull << 32) / (uint64_t)a.qkv_S) + 1u : 0u;
+    const int div = EPI == EPI_PATCH16 ? a.patch_P : a.qkv_S;
+    const uint32_t magic = div > 0 ? (uint32_t)((1ull << 32) / (uint64_t)div) + 1u : 0u;
     Gemm16Args b = a;
     // the panel walk needs at least one row tile per XCD slab and a panel narrower than the tile row
     if (b.walk_c >= tiles_n || tiles_m < 8 || b.walk_c < 0) b.walk_c = 0;
@@ -631,14 +638,15 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
         case EPI_OUT16: return launch_epi<T, EPI_OUT16>(a, s);
         case EPI_GELU16: return launch_epi<T, EPI_GELU16>(a, s);
         case EPI_QKVH16: return launch_epi<T, EPI_QKVH16>(a, s);
-        default: iisan_set_error("gemm16_s256: epilogue mode %d not supported", mode); return IISAN_EBADSHAPE;
+        case EPI_PATCH16: return launch_epi<T, EPI_PATCH16>(a, s);
+        default: iisan_set_error("gemm16_h256: epilogue mode %d not supported", mode); return IISAN_EBADSHAPE;
     }
 }
 
 }  // namespace
 
 bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
-    if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
+    if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16 || mode == EPI_PATCH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
         return false;
     const int64_t rows = ceil_div(a.M, SBM) * SBM;
@@ -647,6 +655,8 @@ bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
                                  // K/V-only product of the CLS-pruned last block still addresses the full tensor) — ADVICE r3: the bound
                                  // used (3 - which0) and let row counts in [932k, 1.40M) wrap at 12 heads
         return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && rows * 3 * (int64_t)a.qkv_heads * 128 + 128 < (1ll << 32);
+    if (mode == EPI_PATCH16)     // 32-bit byte offsets of the remapped rows, exact reciprocal division
+        return a.patch_P > 0 && rows * a.patch_P < (1ll << 32) && (rows + rows / a.patch_P + 2) * (int64_t)a.ldo * 2 < (1ll << 32);
     return (int64_t)a.ldo * 2 * 16 + 64 < (1ll << 31);       // the 32-bit lane offset of a 16-row store
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
                                                                  const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                                  typename T::elem* __restrict__ out16, int64_t items, int Ttok) {
     constexpr bool D1 = (V & MX_D1) != 0, D2 = (V & MX_D2) != 0, LN = (V & MX_LN) != 0, RESV = (V & MX_RESV) != 0,
-                   RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0;
+                   RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0, POSROW = (V & MX_POSROW) != 0;
     typedef typename T::v8 V8;
     const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;          // 8 half-waves per workgroup
     int64_t item;
@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
     } else if (SRC32) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const f4 a = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 8));
-            const f4 c = __builtin_nontemporal_load((const f4*)(x32 + row * 768 + i * 256 + lane * 8 + 4));
+            const int64_t srow = POSROW ? (int64_t)tok : row;            // POSROW: the position-embedding table (L2-resident), by token
+            const f4 a = POSROW ? *(const f4*)(x32 + srow * 768 + i * 256 + lane * 8) : __builtin_nontemporal_load((const f4*)(x32 + srow * 768 + i * 256 + lane * 8));
+            const f4 c = POSROW ? *(const f4*)(x32 + srow * 768 + i * 256 + lane * 8 + 4) : __builtin_nontemporal_load((const f4*)(x32 + srow * 768 + i * 256 + lane * 8 + 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = c[e]; }
         }
@@ -160,17 +161,18 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
         }
     };
     float s = 0.f;
+    const bool use_d = !(POSROW && cls);          // POSROW: the CLS slot of the patch-embedding buffer was never written
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (D1) {
+        if (D1 && use_d) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[i][e] += T::to_f32(d1[i][e]);
         }
-        if (D2) {       // added AFTER delta, in fp32: (x + delta) + delta2
+        if (D2 && use_d) {       // added AFTER delta, in fp32: (x + delta) + delta2
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[i][e] += T::to_f32(d2[i][e]);
         }
-        if (RESV) put_resid(i, v[i]);
+        if (RESV && !(POSROW && cls)) put_resid(i, v[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[i][e];
     }
@@ -390,6 +392,7 @@ int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, f
         break
     switch (V) {
         MX_CASE(MX_SRC32 | MX_RESV | MX_LN);               // ViT block 0, LN1: fp32 embeddings -> fp16 stream + LN image
+        MX_CASE(MX_SRC32 | MX_POSROW | MX_D1 | MX_RESV | MX_LN);   // ViT block 0, LN1: position table + 16-bit patch embedding -> stream + image
         MX_CASE(MX_D1 | MX_LN);                            // ViT LN2: LN(x + dO), x not written
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_LN);          // ViT LN1: x += dO + dF; LN
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY);     // ViT closing add of the CLS rows (hidden state 12)
