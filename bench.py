@@ -240,6 +240,17 @@ def cached_line(a, lib, dev, rank, world, steps, warmup):
 SCI_USERS = 12076                # users of Amazon-Scientific after filtering
 
 
+def eval_pmc_traffic(a, world):
+    """HBM-side bytes per `score_rank_mfma_kernel` launch at Scientific size from the committed PMC passes (profiles/pmc_traffic_eval.json,
+    tools/evidence_r4.sh); null unless this is that configuration (one rank, the library's own routes)."""
+    from iisan_amd import _lib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_eval.json")
+    if not os.path.exists(path) or world != 1 or _lib.dev_knobs():
+        return None
+    with open(path) as f:
+        return float(json.load(f)["avg_bytes_per_launch"])
+
+
 def eval_line(a, lib, dev, rank, world, reps=5):
     """The path that produces HR@10 at Scientific size: item table [20,315 x 64] from cached taps (`item_table`), then for
     12,076 users SASRec -> scores against every item -> history mask -> exact rank of the target (`evaluate_ranks`:
@@ -306,7 +317,7 @@ def eval_line(a, lib, dev, rank, world, reps=5):
                                           "[N, 13, 768] fp32 x 2 (reference layout), item batch 2048"},
                    "score_rank_alone": {"users_per_s": U / (ms * 1e-3), "ms_per_launch": ms, "launch": f"{U} users x {n + 1} items"}},
         "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": flops / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": None, "kernel": "score_rank_kernel",
+                     "frac": flops / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": eval_pmc_traffic(a, world), "kernel": "score_rank_mfma_kernel",
                      "launches": len(ev), "avg_launch_ms": ms, "flop_per_launch": flops,
                      "traffic_algorithmic": float((n + 1) * 64 * 4 + U * 64 * 4 + U * 10 * 4 + U * 8)},
     }
