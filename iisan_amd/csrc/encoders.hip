@@ -160,7 +160,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                                   : (const void*)((const float*)images + m0 * img_elems);
         IISAN_TRY(launch_vit_im2col(dt, img0, img_u8, b.F1, mc, w->channels, w->image, w->patch, s));
         const bool mixed = !g_resid32;
-        // patch embedding: resid32 = fp32 token rows with the position embedding added (p256 / v1 kernels); mixed = 16-bit rows on the
+        // patch embedding: resid32 = fp32 token rows with the position embedding added (128x128 kernel); mixed = 16-bit rows on the
         // production GEMM (gemm16_h256, 0.40 against 0.59 ms at bs = 128), the position table is added by block 0's LayerNorm
         if (mixed) IISAN_TRY(gemm(dt, EPI_PATCH16, b.F1, pd, w->patch_w, w->patch_b, b.D16b, D, nullptr, mc * P, s, nullptr, P));
         else IISAN_TRY(gemm(dt, EPI_PATCH32, b.F1, pd, w->patch_w, w->patch_b, b.X, D, nullptr, mc * P, s, w->pos_emb, P));

@@ -244,15 +244,13 @@ extern "C" int iisan_gemm16_f32(const void* A, const void* W, float* out, int64_
     return launch_gemm16_f32(a, ksplit, (hipStream_t)stream);
 }
 
-bool gemm16_p256_applicable(const Gemm16Args& a);
-int launch_gemm16_p256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 bool gemm16_s256_applicable(int mode, const Gemm16Args& a);
 int launch_gemm16_s256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 bool gemm16_h256_applicable(int mode, const Gemm16Args& a);
 int launch_gemm16_h256(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
 
 // 0 = auto (persistent 256x256 kernels when the shape allows and there is at least half a tile per CU), 1 = force the
-// 128x128 v1 kernel, 2 = force the lock-step 256x256 kernel, 3 = force the staggered 256x256 kernel (gemm16_s256.hip), 4 = force
+// 128x128 v1 kernel, (2 = the lock-step 256x256 kernel of round 1, retired in round 4: treated as auto), 3 = force the staggered 256x256 kernel (gemm16_s256.hip), 4 = force
 // the staggered kernel with the half-slot tile boundary (gemm16_h256.hip).
 // Test/bench knob, not part of the product ABI.
 static int g_variant = 0;
@@ -284,7 +282,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const bool timed = iisan_timing_on(s);
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N));
     const int var = g_variant & 0xff;
-    const bool big = var == 2 || var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    const bool big = var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
     if (big && (var == 4 || (var == 0 && g_auto_staggered && g_auto_h256)) && gemm16_h256_applicable(mode, a)) {
         Gemm16Args b = a;
@@ -299,18 +297,16 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
         if (timed) iisan_timing_post(s);
         return rc;
     }
-    // auto policy (micro-benchmarks, tools/gemm_time.py): the staggered kernel wins on all four encoder GEMM shapes;
-    // the lock-step one takes what the staggered one does not cover (fp32 / residual epilogues)
+    // the staggered kernel without the half-slot boundary: variant 3 (the race-screen reference of gemm16_h256) and the shapes
+    // gemm16_h256_applicable() turns down
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
         if (g_desync && (mode == EPI_QKVH16 || mode == EPI_GELU16) && a.K <= 1024) b.debug |= 4;
         rc = launch_gemm16_s256(dtype16, mode, b, s);
-    } else if (big && mode != EPI_PATCH16 && gemm16_p256_applicable(a)) {       // (the 16-bit patch epilogue: gemm16_h256 or the 128x128 kernel)
-        Gemm16Args b = a;
-        b.debug = g_variant >> 8;
-        rc = launch_gemm16_p256(dtype16, mode, b, s);
     }
+    // everything else — small shapes, the fp32 / residual epilogues (round 4 retired the lock-step 256x256 kernel gemm16_p256.hip: its
+    // last product, the patch embedding, runs on gemm16_h256 with a 16-bit output) — on the 128x128 kernel
     else rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
     if (timed) iisan_timing_post(s);
     return rc;

@@ -25,7 +25,7 @@ def _pad_rows(t, mult=256):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1000, 768, 3072), (517, 2304, 768), (70000, 768, 768)])
