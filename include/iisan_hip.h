@@ -178,6 +178,10 @@ int iisan_linear_bwd(const float* x, const float* w, const float* dy, float* dx,
  * params order (host array of device pointers): position_embedding.weight, layer_norm.{weight,bias}, then per
  * block: w_Q, w_K, w_V, fc (weights), attn layer_norm.{weight,bias}, w_1.{weight,bias}, w_2.{weight,bias},
  * ffn layer_norm.{weight,bias}.   x: [B,S,E]; log_mask: [B,S]; y: [B,S,E].
+ * With emb == 64, seq <= 16 and 1, 2 or 4 heads (the reference configuration is 64 / 10 / 2) each direction is ONE launch
+ * (+ a fixed-order reducer of per-workgroup parameter-gradient partial sums in the backward: bit-reproducible, no atomics);
+ * other shapes take one launch per operator.  Either way the forward keeps every intermediate the backward needs in `ws`
+ * (same slots), and gradients ACCUMULATE (+=) into the caller's tensors.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t seq, emb, heads, blocks;       /* 10, 64, 2, 2                                                     */
