@@ -1127,7 +1127,7 @@ def test_cached_default_routes_match_the_cpu_oracle_at_bench_size(lib, bs, act):
     `gemm32_dw_kernel` at M = 11,264 and through the fused `sanb_*_kernel<768>` at M = 704 and M = 1,408 (bs = 128: the side
     network of the Uncached headline).  With ReLU a 1e-7 difference in a pre-activation near zero flips a unit and moves SINGLE
     gradient elements by 1e-3 of the tensor's scale whatever the kernels do, so the ReLU cases hold every tensor in the
-    Frobenius norm (3e-4 of its norm; robust to unit flips), the loss at 2e-5 as before.
+    Frobenius norm (5e-5 of its norm — measured 3.2e-6 worst; robust to unit flips), the loss at 2e-5 as before.
     Reference: `Code_Cached/model/model.py:300-349`, `Code_Uncached/model/model.py:81-104`."""
     from iisan_amd import tapstore
     n = 2000
@@ -1166,11 +1166,11 @@ def test_cached_default_routes_match_the_cpu_oracle_at_bench_size(lib, bs, act):
             gates.setdefault(k.rsplit(".", 1)[0], []).append((p.grad.cpu().reshape(-1).double(), go.reshape(-1).double()))
         else:
             err = ((p.grad.cpu().double() - go.double()).norm() / (go.double().norm() + 1e-30)).item()
-            assert err < (2e-3 if "user_encoder" in k else 3e-4), (k, err)
+            assert err < 5e-5, (k, err)        # measured on MI355X: 3.2e-6 worst over the 146 tensors at every batch size
         n_checked += 1
     for tower, pairs in gates.items():
         g1, g0 = torch.cat([a for a, _ in pairs]), torch.cat([c for _, c in pairs])
-        assert ((g1 - g0).norm() / g0.norm()).item() < 2e-3, (tower, ((g1 - g0).norm() / g0.norm()).item())
+        assert ((g1 - g0).norm() / g0.norm()).item() < 5e-5, (tower, ((g1 - g0).norm() / g0.norm()).item())
     assert n_checked == 146
 
 
