@@ -429,7 +429,11 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     typedef typename T::elem E;
     // heads per workgroup: 2 (one head computing, the next one's Q/K/V in flight).  On the spill-free kernel 1 / 2 / 4 / 6
     // heads measured 420 / 421 / 428 / 437 us per ViT layer in isolation and 68.55 / 68.58 / 68.78 ms per step
-    const int hpw = heads % 2 == 0 ? 2 : 1;
+    int hpw = heads % 2 == 0 ? 2 : 1;
+    {   // development knob (tools/attn_pf_ab.py): bits 8..11 of iisan_set_attn_debug = heads per workgroup, when it divides the head count
+        const int want = (g_attn_dbg >> 8) & 15;
+        if (want > 0 && heads % want == 0) hpw = want;
+    }
     dim3 grid((unsigned)(items * (heads / hpw))), block(256);
     // g_attn_dbg bit 5 (32): the three-workgroups-per-CU kernel without register prefetch (A/B knob, tools/attn_pf_ab.py: same-process
     // rounds on the ViT shape 415-421 us against 398-411 us for the prefetching kernel with two workgroups per CU — the default; both

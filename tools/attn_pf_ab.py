@@ -30,4 +30,19 @@ for name, S, bias in (("vit", 197, False), ("bert", 30, True)):
             for _ in range(20): lib.iisan_attention16(0, qkv.data_ptr(), kb.data_ptr() if bias else None, ctx.data_ptr(), items, S, heads, st)
             torch.cuda.synchronize()
             print(f"  round {r} {name} {'no-prefetch/3wg' if dbg else 'prefetch/2wg'}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us", flush=True)
+# heads per workgroup x prefetch variant (ViT shape)
+items, heads, S = 1408, 12, 197
+qkv = torch.randn(items, heads, 3, S, 64, device="cuda").half()
+ctx = torch.empty(items * S, heads * 64, device="cuda", dtype=torch.float16)
+for r in range(2):
+    for pf in (0, 32):
+        row = []
+        for hpw in (1, 2, 3, 4, 6):
+            lib.iisan_set_attn_debug(pf | (hpw << 8))
+            for _ in range(3): lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
+            torch.cuda.synchronize()
+            row.append(f"hpw {hpw}: {(time.perf_counter() - t0) / 20 * 1e6:.0f}")
+        print(f"  round {r} {'no-prefetch/3wg' if pf else 'prefetch/2wg'}: " + "  ".join(row), flush=True)
 lib.iisan_set_attn_debug(0)
