@@ -91,6 +91,9 @@ EXTRA_SIGNATURES = {
     "iisan_set_gemm16_walk": (None, [i32, i32]),
     "iisan_gemm16_h256_applicable": (i32, [i32, i64, i32, i32, i32, i32, i32]),
     "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "iisan_gemm16_lna": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "iisan_fold_ln_weights": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    "iisan_set_ln_fold": (None, [i32]),
     "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_gemm16_h256": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),

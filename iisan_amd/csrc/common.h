@@ -246,6 +246,12 @@ struct Gemm16Args {
     int32_t qkv_which0;         // EPI_QKVH16: first of q|k|v (0..2) the N = (3 - which0)*64*heads columns hold (1 = K and V only)
     int32_t debug;      // ablation bits for micro-benchmarks: 1 = skip epilogue stores, 2 = skip steady-state DMA
     int32_t walk_c, walk_h;     // gemm16_h256 tile walk: panels of walk_c column tiles, sub-slabs of walk_h row tiles per XCD (0 = row-major list)
+    // LayerNorm applied ALGEBRAICALLY in the epilogue (gemm16_h256 only, EPI_QKVH16 / EPI_GELU16, fp16 operands): A holds the
+    // un-normalised rows x, W the folded rows Wf[n][k] = gamma[k] W[n][k] - mean_k(gamma W[n]) (fold_ln_weights: centred, so that
+    // sum_k x[k] Wf[n][k] = sum_k (x[k] - mean(x)) gamma[k] W[n][k]), and
+    //     LN(x) W^T + b  =  rstd_m * acc[m][n] + bias'[n],     bias' = b + W beta (in `bias`)
+    // rowstat = [Mpad] fp32: rstd of every row of A; null = plain product
+    const float* rowstat;
     // EPI_F32 (split-operand GEMM of the trainable path, split.hip): out fp32 = acc * inv_a[0] * inv_b[0] (+ bias) (+ resid)
     const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
     int32_t atomic;     // 1: accumulate into out with fp32 atomics (bench knob only: ~20 G atomics/s chip-wide, far too slow)
@@ -258,6 +264,7 @@ enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
 // slice the attention kernel streams is then one contiguous block instead of 128-byte pieces at a 4.6 KB stride.
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a);   // gemm16.hip: would this product run on the kernel that applies LayerNorm in its epilogue?
 int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
                         float* out32, int64_t rows, hipStream_t s);
 // x (+ delta16) -> [sum32 = x + delta] -> LayerNorm -> out16 / out32 (any output may be null; g == null: no LayerNorm)
@@ -268,11 +275,18 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
                              const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 // mixed-precision residual stream (rowops.hip: layernorm768_mixed_kernel): CLS rows fp32 in `xc` [items, 768], every other token
 // row fp16 in `x16` [items * Ttok, 768]; V = which operands exist
-enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64, MX_POSROW = 128 };
+enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64, MX_POSROW = 128, MX_STAT = 256 };
+// MX_STAT (with MX_RESV, without MX_LN): no LayerNorm image; every row's sum goes to the fp16 stream (the CLS rows as well: the stream
+// is the next GEMM's A operand) and `stat` [rows] receives rstd of the ROUNDED row — Gemm16Args::rowstat
 // MX_POSROW (with MX_SRC32 | MX_D1): the fp32 source is a [Ttok, 768] table indexed by the TOKEN (the position embedding) and the delta is
 // the patch embedding of that token; CLS rows take neither (their stream holds cls + pos[0] already)
 int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
-                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s);
+                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s,
+                              float* stat = nullptr);
+// LayerNorm folded into the weights of the product that consumes it (rowops.hip): Wf[n][k] = fp16(gamma[k] W[n][k] - mean_k(gamma W[n]))
+// with sum_k Wf[n][k] = 0 to the last bit that matters, bf[n] = bias[n] + sum_k beta[k] W[n][k]; K = 768, fp16 weights.  Up to 32 jobs in one launch.
+struct LnFoldJob { const void* W; const float* bias; const float* g; const float* b; void* Wf; float* bf; int32_t N; };
+int launch_fold_ln_weights(const LnFoldJob* jobs, int n, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)

@@ -28,13 +28,22 @@ struct EncBufs {
     float* KB;      // [Mc, W] key bias (BERT)
     void* Cls;      // [2, Mcp, D] 16-bit: CLS rows of LN(x) and their Q projection in the CLS-only last block
     int64_t Mcp;    // items per chunk rounded up to a GEMM row tile
+    // LayerNorm applied by the consuming product (ViT, fp16, mixed stream; g_ln_fold):
+    void* Wf;       // [layers][3D + F, D] fp16: gamma-folded, centred QKV and FC1 weights
+    float* Bf;      // [layers][3D + F]: folded biases
+    float* RS;      // [Tp]: rstd of every row of the stream
 };
 
 // 1 = keep the whole residual stream in fp32 (rounds 1-3); 0 (default) = fp32 for the CLS rows, fp16 for the others (rowops.hip).
 // Bench / test knob (tools/enc_time.py A/B, tests/test_gpu_encoders.py); the *_ws_bytes queries follow it.
 int g_resid32 = 0;
+// 1 (default): the pre-LN tower (ViT) with fp16 operands and the mixed stream never materialises LayerNorm(x): the add kernels write
+// the stream and rstd per row, the QKV / FC1 products read the stream itself against gamma-folded, centred weights and apply
+// rstd in their epilogues (Gemm16Args::rowstat) — 12 instead of 16 bytes per token row and block in the HBM-bound kernels.
+// 0: the LayerNorm image of rounds 1-4.  Bench / test knob.
+int g_ln_fold = 1;
 
-size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems) {
+size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems, int fold_layers = 0) {
     const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
     b.Mcp = ceil_div(items, 256) * 256;
     b.Cls = c.take<uint16_t>((size_t)2 * b.Mcp * D);
@@ -48,17 +57,37 @@ size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int 
     b.D16 = c.take<uint16_t>((size_t)Tp * D);
     b.D16b = c.take<uint16_t>((size_t)Tp * D);
     b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
+    b.Wf = nullptr; b.Bf = nullptr; b.RS = nullptr;
+    if (fold_layers > 0) {
+        b.Wf = c.take<uint16_t>((size_t)fold_layers * (3 * D + F) * D);
+        b.Bf = c.take<float>((size_t)fold_layers * (3 * D + F));
+        b.RS = c.take<float>((size_t)Tp);
+    }
     return c.off;
+}
+
+Gemm16Args gemm_args(int mode, const void* A, int K, const void* W, const float* bias, void* out, int N, int64_t M, int qkv_S = 0,
+                     int qkv_heads = 0, int qkv_which0 = 0, const float* rowstat = nullptr) {
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N;
+    a.qkv_S = qkv_S; a.qkv_heads = qkv_heads; a.qkv_which0 = qkv_which0;
+    a.rowstat = rowstat;
+    return a;
 }
 
 int gemm(int dt, int mode, const void* A, int K, const void* W, const float* bias, void* out, int N, const float* resid,
          int64_t M, hipStream_t s, const float* pos = nullptr, int patch_P = 0, int qkv_S = 0, int qkv_heads = 0,
          int qkv_which0 = 0) {
-    Gemm16Args a{};
-    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.pos = pos;
-    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.patch_P = patch_P;
-    a.qkv_S = qkv_S; a.qkv_heads = qkv_heads; a.qkv_which0 = qkv_which0;
+    Gemm16Args a = gemm_args(mode, A, K, W, bias, out, N, M, qkv_S, qkv_heads, qkv_which0);
+    a.resid = resid; a.pos = pos; a.patch_P = patch_P;
     return launch_gemm16(dt, mode, a, s);
+}
+
+// LN(x) W^T + b with the LayerNorm in the epilogue: A = the stream, W / bias = the folded set, rowstat = the rows' rstd
+int gemm_ln(int dt, int mode, const void* X16, int K, const void* Wf, const float* bf, const float* rs, void* out, int N,
+            int64_t M, hipStream_t s, int qkv_S = 0, int qkv_heads = 0, int qkv_which0 = 0) {
+    return launch_gemm16(dt, mode, gemm_args(mode, X16, K, Wf, bf, out, N, M, qkv_S, qkv_heads, qkv_which0, rs), s);
 }
 
 // Last live block: K and V for every token (head-major; the q third of the buffer is left untouched), Q for the CLS rows
@@ -104,6 +133,10 @@ int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const i
 
 extern "C" void iisan_set_full_blocks(int32_t on) { g_full_blocks = on; }
 extern "C" void iisan_set_resid32(int32_t on) { g_resid32 = on; }
+extern "C" void iisan_set_ln_fold(int32_t on) { g_ln_fold = on; }
+static int vit_fold_layers(const iisan_vit_weights* w) {
+    return (!g_resid32 && g_ln_fold && w->dtype16 == IISAN_F16) ? w->layers : 0;
+}
 
 extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items) {
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
@@ -111,7 +144,7 @@ extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, in
     const int pd = w->channels * w->patch * w->patch;
     WsCarver c(nullptr, 0);
     EncBufs b;
-    return carve(c, b, Mc * (P + 1), Mc, w->hidden, w->mlp > pd ? w->mlp : pd, 0);
+    return carve(c, b, Mc * (P + 1), Mc, w->hidden, w->mlp > pd ? w->mlp : pd, 0, vit_fold_layers(w));
 }
 
 static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images, int img_u8, int64_t M,
@@ -145,12 +178,38 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
     WsCarver c(ws, ws_bytes);
     EncBufs b;
-    carve(c, b, Mc * T, Mc, D, F > pd ? F : pd, 0);
+    carve(c, b, Mc * T, Mc, D, F > pd ? F : pd, 0, vit_fold_layers(w));
     if (c.overflow || !ws) {
         iisan_set_error("vit_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
     }
     const int dt = w->dtype16;
+    const bool full_blocks = g_full_blocks || w->full_blocks;
+    const int live = full_blocks ? w->layers : max_tap(tap_layers, n_taps);
+    // LayerNorm in the epilogues of the QKV / FC1 products (g_ln_fold): only where those products run on the kernel that has it, for
+    // every chunk size of this call (the last chunk may be shorter)
+    bool lna = b.Wf != nullptr && live > 0;
+    for (int64_t mc : {Mc, M % Mc == 0 ? Mc : M % Mc}) {
+        const int64_t tok = mc * T;
+        lna = lna && gemm16_takes_rowstat(dt, EPI_QKVH16, gemm_args(EPI_QKVH16, nullptr, D, nullptr, nullptr, nullptr, 3 * D, tok, T, w->heads)) &&
+              gemm16_takes_rowstat(dt, EPI_GELU16, gemm_args(EPI_GELU16, nullptr, D, nullptr, nullptr, nullptr, F, tok)) &&
+              (full_blocks || gemm16_takes_rowstat(dt, EPI_QKVH16, gemm_args(EPI_QKVH16, nullptr, D, nullptr, nullptr, nullptr, 2 * D, tok, T, w->heads, 1)));
+    }
+    const size_t fold_w = (size_t)(3 * D + F) * D;          // elements of one layer's folded weights
+    auto Wf_qkv = [&](int l) { return (char*)b.Wf + (size_t)l * fold_w * 2; };
+    auto Wf_fc1 = [&](int l) { return Wf_qkv(l) + (size_t)3 * D * D * 2; };
+    auto bf_qkv = [&](int l) { return b.Bf + (size_t)l * (3 * D + F); };
+    auto bf_fc1 = [&](int l) { return bf_qkv(l) + 3 * D; };
+    if (lna) {
+        LnFoldJob jobs[32];
+        int nj = 0;
+        for (int l = 0; l < live; ++l) {
+            const iisan_layer_weights& L = w->layer[l];
+            jobs[nj++] = LnFoldJob{L.qkv_w, L.qkv_b, L.ln1_w, L.ln1_b, Wf_qkv(l), bf_qkv(l), 3 * D};
+            if (l + 1 < live || full_blocks) jobs[nj++] = LnFoldJob{L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, Wf_fc1(l), bf_fc1(l), F};
+            if (nj >= 31 || l + 1 == live) { IISAN_TRY(launch_fold_ln_weights(jobs, nj, s)); nj = 0; }
+        }
+    }
     const int64_t img_elems = (int64_t)w->channels * w->image * w->image;
     for (int64_t m0 = 0; m0 < M; m0 += Mc) {
         const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;
@@ -179,12 +238,18 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         // Blocks after the deepest tapped hidden state are dead code (Versa configurations tap a prefix of the tower),
         // and in the last LIVE block only the CLS token's output is consumed: K/V are computed for every token, but
         // attention, O, LN2, FC1, FC2 and the closing residual add run on one row per item.
-        const bool full_blocks = g_full_blocks || w->full_blocks;
-        const int live = full_blocks ? w->layers : max_tap(tap_layers, n_taps);
+        constexpr int MX_ADD_STAT = MX_D1 | MX_RESV | MX_STAT;       // x += d (fp16 stream, fp32 CLS rows); row statistics
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
             // x += pending deltas of block l-1 ; h = LN1(x)            -> the stream is hidden state l
-            if (!mixed)
+            if (lna) {
+                // ... without the image h: the stream + (rstd, -mean rstd) per row; LN1 is applied by the QKV product's epilogue.
+                // (x + dO is in the stream already: this block's predecessor wrote it in its LN2 step)
+                if (l == 0)
+                    IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_POSROW | MX_ADD_STAT, w->pos_emb, b.X16, b.Xc, b.D16b, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s, b.RS));
+                else
+                    IISAN_TRY(launch_layernorm768_mixed(dt, MX_ADD_STAT, nullptr, b.X16, b.Xc, pend_f, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s, b.RS));
+            } else if (!mixed)
                 IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
             else if (l == 0)     // position table + 16-bit patch embedding -> fp16 stream of the patch rows (the CLS rows are in Xc already) + LN image
                 IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_POSROW | MX_D1 | MX_RESV | MX_LN, w->pos_emb, b.X16, b.Xc, b.D16b, nullptr, L.ln1_w, L.ln1_b, w->eps, b.H, mc, T, s));
@@ -193,7 +258,16 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
             pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(tap(k));
-            if (l + 1 < live || full_blocks) {
+            if (lna && (l + 1 < live || full_blocks)) {
+                IISAN_TRY(gemm_ln(dt, EPI_QKVH16, b.X16, D, Wf_qkv(l), bf_qkv(l), b.RS, b.QKV, 3 * D, tok, s, T, w->heads));
+                IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
+                // x += dO (written: the FC1 product reads the stream); LN2 in the FC1 product's epilogue
+                IISAN_TRY(launch_layernorm768_mixed(dt, MX_ADD_STAT, nullptr, b.X16, b.Xc, b.D16, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s, b.RS));
+                IISAN_TRY(gemm_ln(dt, EPI_GELU16, b.X16, D, Wf_fc1(l), bf_fc1(l), b.RS, b.F1, F, tok, s));
+                IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16b, D, nullptr, tok, s));
+                pend_f = b.D16b;
+            } else if (l + 1 < live || full_blocks) {
                 IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
@@ -210,8 +284,15 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 // CLS rows only: compact [mc, D] 16-bit views in their own scratch
                 void* Hc = b.Cls;
                 void* Qc = (char*)b.Cls + (size_t)b.Mcp * D * 2;
-                IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));            // CLS rows of LN1(x)
-                IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
+                if (lna) {
+                    // K / V of every token from the stream (LN1 in the epilogue); the CLS rows' LN1 image from their fp32 stream
+                    IISAN_TRY(launch_layernorm768(dt, b.Xc, L.ln1_w, L.ln1_b, w->eps, Hc, nullptr, mc, s));
+                    IISAN_TRY(gemm_ln(dt, EPI_QKVH16, b.X16, D, Wf_qkv(l) + (size_t)D * D * 2, bf_qkv(l) + D, b.RS, b.QKV, 2 * D, tok, s, T, w->heads, 1));
+                    IISAN_TRY(gemm(dt, EPI_OUT16, Hc, D, L.qkv_w, L.qkv_b, Qc, D, nullptr, mc, s));
+                } else {
+                    IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));            // CLS rows of LN1(x)
+                    IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
+                }
                 IISAN_TRY(launch_attention_cls16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s, Qc));
                 float* Xc = (float*)b.QKV;      // free once the CLS attention has run (stream order)
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));
@@ -227,7 +308,9 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         if (full_blocks) {
             k = tap_index(tap_layers, n_taps, w->layers);
             if (k >= 0) {
-                if (!mixed)
+                if (lna)        // x + dO is in the stream: the CLS rows take dF
+                    IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_RESV | MX_CLSONLY, nullptr, b.X16, b.Xc, pend_f, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s));
+                else if (!mixed)
                     IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));
                 else            // only the CLS rows of the last hidden state are consumed
                     IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY, nullptr, b.X16, b.Xc, pend_o, pend_f, nullptr, nullptr, w->eps, nullptr, mc, T, s));

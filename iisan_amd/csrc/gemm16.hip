@@ -297,6 +297,8 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
         if (timed) iisan_timing_post(s);
         return rc;
     }
+    IISAN_CHECK_SHAPE(!a.rowstat, "gemm16: a product with LayerNorm row statistics runs on gemm16_h256 only (mode %d, M=%lld N=%d K=%d, variant %d)",
+                      mode, (long long)a.M, a.N, a.K, var);
     // the staggered kernel without the half-slot boundary: variant 3 (the race-screen reference of gemm16_h256) and the shapes
     // gemm16_h256_applicable() turns down
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
@@ -310,6 +312,36 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     else rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
     if (timed) iisan_timing_post(s);
     return rc;
+}
+
+// would launch_gemm16 run this product on the kernel that applies LayerNorm in its epilogue (Gemm16Args::rowstat)?  The encoder
+// executors ask BEFORE they choose between the algebraic and the materialised LayerNorm; mirrors the routing above.
+bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a) {
+    const int var = g_variant & 0xff;
+    const bool big = var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    Gemm16Args b = a;
+    static const float dummy = 0.f;
+    if (!b.rowstat) b.rowstat = &dummy;
+    return dtype16 == IISAN_F16 && big && (var == 4 || (g_auto_staggered && g_auto_h256)) && a.N % BN == 0 && a.K % BK == 0 &&
+           gemm16_h256_applicable(mode, b);
+}
+
+// bench / test entry (not in the product ABI): LN(x) W^T + b with the LayerNorm applied in the epilogue — A = x [M, K] fp16,
+// W = the folded weights, rowstat [Mpad] (null: plain product); mode 1 (GELU) or 4 (head-major QKV: S tokens per item, N / 192 heads)
+extern "C" int iisan_gemm16_lna(int32_t mode, const void* A, const void* W, const float* bias, void* out, const float* rowstat,
+                                int64_t M, int32_t N, int32_t K, int32_t S, void* stream) {
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.rowstat = rowstat;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N;
+    if (mode == EPI_QKVH16) { a.qkv_S = S; a.qkv_heads = N / 192; }
+    return launch_gemm16(IISAN_F16, mode, a, (hipStream_t)stream);
+}
+
+// bench / test entry: the weight fold of one LayerNorm + product pair (rowops.hip)
+extern "C" int iisan_fold_ln_weights(const void* W, const float* bias, const float* g, const float* b, void* Wf, float* bf,
+                                     int32_t N, void* stream) {
+    LnFoldJob j{W, bias, g, b, Wf, bf, N};
+    return launch_fold_ln_weights(&j, 1, (hipStream_t)stream);
 }
 
 extern "C" int iisan_gemm16(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out,

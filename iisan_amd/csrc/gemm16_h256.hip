@@ -47,6 +47,9 @@ constexpr int SBM = 256, SBN = 256, SBK = 64;
 constexpr int S_OP_BYTES = SBM * SBK * 2;        // 32 KiB per operand tile
 constexpr int S_STAGE_BYTES = 2 * S_OP_BYTES;    // 64 KiB per K-step
 constexpr int STG_BIAS_BYTES = 8192 * 4;           // LDS after the ring: the layer's bias vector (N <= 8192 floats; 160 KiB in all)
+// LNA (LayerNorm applied in the epilogue, Gemm16Args::rowstat): two 1-KiB buffers of row statistics (rstd of the tile's 256 rows, one
+// buffer per tile, alternating) sit at 24 KiB of the bias area
+constexpr int LNA_STAT_OFF = 24576, LNA_MAX_N = 6144;
 constexpr int STG_TILE_BYTES = 0;
 
 template <typename T> struct Mfma32s;
@@ -77,11 +80,12 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
     } while (0)
 #define S256_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0) */
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool LNA>
 __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
     typedef typename T::v8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + up to 8192 floats of bias
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
+    float* sStat = (float*)(smem + 2 * S_STAGE_BYTES + LNA_STAT_OFF);             // LNA: [2][256] row statistics (rstd)
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;      // LDS byte address of the dynamic segment
 
     const int tid = threadIdx.x;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // stores issued from middle read slots then sit in the CU's in-order vector-memory pipeline in front of the LDS-DMA pieces of
     // the next MFMA slot, which land late: middle slots of 1,500-2,200 cycles appeared and the kernel lost 7 % (QKV 928 against
     // 998 TFLOP/s).  The vector-memory path (128 stores x 92 + 768 DMA pieces per tile) is as busy as the matrix pipe.
-    auto epilogue = [&](int tm, int tn, int half) {
+    auto epilogue = [&](int tm, int tn, int half, int sbuf) {
         // The lane-dependent offsets are RECOMPUTED here from a laundered lane id: hoisted out of the K loop they stay live
         // across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is followed by an
         // `s_waitcnt vmcnt(0)` — which also waits for the LDS-DMA in flight and the stores.
@@ -401,14 +405,38 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int mi = 2 * half + (b & 1), ni = b >> 1;
-                    if ((b & 1) == 0) {
+                    f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
+                    if (!LNA && (b & 1) == 0) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
                     }
-                    f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
+                    if constexpr (LNA) {
+                        // rstd_m acc + bias'_n (the weights are gamma-folded AND centred, rowops.hip: the mean term is gone): one v_pk_fma_f32
+                        // per pair where the plain product has a v_pk_add_f32.  The statistic is MATERIALISED as a register pair.  Left to
+                        // the compiler it is broadcast by op_sel straight from the ds_read destination (`v_pk_fma_f32 ..., v[st], ...
+                        // op_sel:[0,1,0]` right behind the `s_waitcnt lgkmcnt(0)`), and in the first version of this epilogue that form
+                        // returned a ZERO product in the low results of lanes 48..63 of the first block of a hi half-epilogue — a few thousand
+                        // of 8.5e8 outputs per launch, different ones every run, with or without the statistics DMA in flight
+                        // (tools/gemm_lna.py checks every element); with the v_mov in between: clean over every run made since.
+                        // (the bias is re-read from LDS per block, eight columns at a time, behind a scheduling fence: held across the two
+                        //  row blocks as in the plain epilogue it costs the GELU variant the 3 registers it does not have)
+                        S256_FENCE();
+                        const float st = sStat[sbuf * 256 + grp * 128 + mi * 32 + frow];
+                        f2 sx = (f2){st, st};
+                        asm volatile("" : "+v"(sx));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        g[k] = (f2){acc[mi][ni][2 * k], acc[mi][ni][2 * k + 1]} + (f2){bbv[k >> 1][2 * (k & 1)], bbv[k >> 1][2 * (k & 1) + 1]};
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const f4 b0 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf), b1 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf + 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                g[4 * hf + k] = __builtin_elementwise_fma((f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]}, sx,
+                                                                          k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            g[k] = (f2){acc[mi][ni][2 * k], acc[mi][ni][2 * k + 1]} + (f2){bbv[k >> 1][2 * (k & 1)], bbv[k >> 1][2 * (k & 1) + 1]};
+                    }
                     // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live
                     //  across this slot, and spilled)
                     if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
@@ -496,6 +524,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     }
     for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias ? p.bias[i] : 0.f;
     __syncthreads();
+    // LNA: the row statistics of the workgroup's ti-th tile (rstd of its 256 rows) come in by LDS-DMA, ONE 1-KiB instruction per tile
+    // (wave 0 of group A: lane i brings rows 4i .. 4i+3), issued at the top of the tile's first [Rhi + E] slot of group A — OLDER
+    // than that slot's 8 stores, so the slot's own `vmcnt(8)` covers it, and the barrier behind that wait publishes it a whole
+    // epilogue before its first reader (group A's lo half-epilogue one K-step later at the earliest; group B runs a slot behind).
+    // Two buffers: the previous tile's hi half-epilogues (A in this slot, B in the next) read the other one.
+    auto stat_dma = [&](int tm, int sbuf) {
+        if constexpr (LNA) {
+            if (grp == 0 && wq == 0)
+                glds16((const char*)p.rowstat + ((int64_t)tm * SBM + 4 * lane) * 4, (char*)sStat + sbuf * 1024);
+        }
+    };
 
     // ---- prologue: what the steady-state rules would have issued before slot 0 ----
     if (grp == 0) {
@@ -536,7 +575,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            if (s > 0) epilogue(prev_tm, prev_tn, 1);
+            stat_dma(cur_tm, ti & 1);
+            if (s > 0) epilogue(prev_tm, prev_tn, 1, (ti - 1) & 1);
             read_hi(s);
             S256_LGKM0();
             // the 8 pieces of Mlo (and, older, the 8 stores of the lo half); the 8 stores just issued stay in flight
@@ -575,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             stamp();
             S256_BARRIER();
             stamp();
-            epilogue(cur_tm, cur_tn, 0);
+            epilogue(cur_tm, cur_tn, 0, ti & 1);
             read_hi(s);
             S256_LGKM0();
             if (stores8) S256_VMCNT(8); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
@@ -593,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             if (ti + 1 < my_tiles) walk(ti + 1, nxt_tm, nxt_tn);
         }
     }
-    epilogue(prev_tm, prev_tn, 1);     // the last tile's hi rows
+    epilogue(prev_tm, prev_tn, 1, (ti - 1) & 1);     // the last tile's hi rows
     if (grp == 0) S256_BARRIER();      // matches B's last slot
 #ifdef S256_TIMELINE
     if (dbg_on && lane == 0)
@@ -608,10 +648,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool LNA = false>
 int launch_epi(const Gemm16Args& a, hipStream_t s) {
     static OncePerDevice attr;
-    auto kern = gemm16_h256_kernel<T, EPI>;
+    auto kern = gemm16_h256_kernel<T, EPI, LNA>;
     constexpr int LDS = 2 * S_STAGE_BYTES + STG_BIAS_BYTES + STG_TILE_BYTES;       // 160 KiB: the whole LDS of a CU
     if (attr.first())
         IISAN_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -634,6 +674,14 @@ int launch_epi(const Gemm16Args& a, hipStream_t s) {
 
 template <typename T>
 int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
+    if (a.rowstat) {         // LayerNorm in the epilogue: fp16 operands, the two products that follow a LayerNorm
+        if constexpr (std::is_same<T, F16>::value) {
+            if (mode == EPI_QKVH16) return launch_epi<F16, EPI_QKVH16, true>(a, s);
+            if (mode == EPI_GELU16) return launch_epi<F16, EPI_GELU16, true>(a, s);
+        }
+        iisan_set_error("gemm16_h256: row statistics with epilogue mode %d / bf16 operands not supported", mode);
+        return IISAN_EBADSHAPE;
+    }
     switch (mode) {
         case EPI_OUT16: return launch_epi<T, EPI_OUT16>(a, s);
         case EPI_GELU16: return launch_epi<T, EPI_GELU16>(a, s);
@@ -649,6 +697,7 @@ bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
     if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16 || mode == EPI_PATCH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
         return false;
+    if (a.rowstat && !((mode == EPI_QKVH16 || mode == EPI_GELU16) && a.N <= LNA_MAX_N)) return false;
     const int64_t rows = ceil_div(a.M, SBM) * SBM;
     if (mode == EPI_QKVH16)      // 32-bit byte offsets into the head-major tensor, exact reciprocal division.  The layout is always
                                  // [item][head][q|k|v][S][64]: element-row index R reaches rows * 3 * heads WHATEVER qkv_which0 is (a

@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
                                                                  const typename T::elem* __restrict__ delta,
                                                                  const typename T::elem* __restrict__ delta2,
                                                                  const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                                 typename T::elem* __restrict__ out16, int64_t items, int Ttok) {
+                                                                 typename T::elem* __restrict__ out16, int64_t items, int Ttok,
+                                                                 float* __restrict__ stat) {
     constexpr bool D1 = (V & MX_D1) != 0, D2 = (V & MX_D2) != 0, LN = (V & MX_LN) != 0, RESV = (V & MX_RESV) != 0,
-                   RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0, POSROW = (V & MX_POSROW) != 0;
+                   RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0, POSROW = (V & MX_POSROW) != 0,
+                   STAT = (V & MX_STAT) != 0;
     typedef typename T::v8 V8;
     const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;          // 8 half-waves per workgroup
     int64_t item;
@@ -149,15 +151,23 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[i][e] = (float)xh[i][e];
     }
-    auto put_resid = [&](int i, const float (&val)[8]) {
+    // STAT: the fp16 stream is the next product's A operand — the CLS rows go there too, and the statistics are those of the
+    // ROUNDED row (what the product multiplies); val is rounded in place
+    auto put_resid = [&](int i, float (&val)[8]) {
         if (cls) {
             *(f4*)(xc + item * 768 + i * 256 + lane * 8) = (f4){val[0], val[1], val[2], val[3]};
             *(f4*)(xc + item * 768 + i * 256 + lane * 8 + 4) = (f4){val[4], val[5], val[6], val[7]};
-        } else {
+        }
+        if (!cls || STAT) {
             h8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (_Float16)val[e];
-            __builtin_nontemporal_store(o, (h8*)(x16 + row * 768 + i * 256 + lane * 8));
+            if (STAT) *(h8*)(x16 + row * 768 + i * 256 + lane * 8) = o;      // read again by the GEMM that follows
+            else __builtin_nontemporal_store(o, (h8*)(x16 + row * 768 + i * 256 + lane * 8));
+            if (STAT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = (float)o[e];
+            }
         }
     };
     float s = 0.f;
@@ -172,11 +182,11 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[i][e] += T::to_f32(d2[i][e]);
         }
-        if (RESV && !(POSROW && cls)) put_resid(i, v[i]);
+        if (RESV && (STAT || !(POSROW && cls))) put_resid(i, v[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[i][e];
     }
-    if (!LN) return;
+    if (!LN && !STAT) return;
     auto sum32 = [](float t) {          // over the 32 lanes of the half-wave
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
@@ -192,6 +202,10 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
             q += d * d;
         }
     const float rstd = rsqrtf(sum32(q) * (1.0f / 768.0f) + eps);
+    if (STAT) {
+        if (lane == 0) stat[row] = rstd;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = i * 256 + lane * 8;
@@ -378,17 +392,19 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
 
 // mixed-precision residual stream (layernorm768_mixed_kernel): V = MX_* flags of the operands that exist
 int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, float* xc, const void* delta16, const void* delta16b,
-                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s) {
+                              const float* g, const float* b, float eps, void* out16, int64_t items, int Ttok, hipStream_t s,
+                              float* stat) {
     if (items <= 0) return IISAN_OK;
+    IISAN_CHECK_SHAPE(!(V & MX_STAT) || stat, "layernorm768_mixed: MX_STAT needs the statistics buffer");
     const int64_t blocks = (V & MX_CLSONLY) ? ceil_div(items, 8) : items * ((Ttok + 7) / 8);
     IISAN_CHECK_SHAPE(blocks < (1ll << 31), "layernorm768_mixed: grid too large");
     dim3 grid((unsigned)blocks), block(256);
 #define MX_CASE(VV)                                                                                                            \
     case VV:                                                                                                                   \
         if (dtype16 == IISAN_BF16)                                                                                             \
-            hipLaunchKernelGGL((layernorm768_mixed_kernel<BF16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, (__bf16*)out16, items, Ttok); \
+            hipLaunchKernelGGL((layernorm768_mixed_kernel<BF16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const __bf16*)delta16, (const __bf16*)delta16b, g, b, eps, (__bf16*)out16, items, Ttok, stat); \
         else                                                                                                                   \
-            hipLaunchKernelGGL((layernorm768_mixed_kernel<F16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, (_Float16*)out16, items, Ttok); \
+            hipLaunchKernelGGL((layernorm768_mixed_kernel<F16, VV>), grid, block, 0, s, x32, (_Float16*)x16, xc, (const _Float16*)delta16, (const _Float16*)delta16b, g, b, eps, (_Float16*)out16, items, Ttok, stat); \
         break
     switch (V) {
         MX_CASE(MX_SRC32 | MX_RESV | MX_LN);               // ViT block 0, LN1: fp32 embeddings -> fp16 stream + LN image
@@ -397,6 +413,10 @@ int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, f
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_LN);          // ViT LN1: x += dO + dF; LN
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY);     // ViT closing add of the CLS rows (hidden state 12)
         MX_CASE(MX_D1 | MX_LN | MX_RESY);                  // BERT: x = LN(x + d)
+        // LayerNorm applied by the consuming product (Gemm16Args::rowstat): the stream and the row statistics only
+        MX_CASE(MX_SRC32 | MX_POSROW | MX_D1 | MX_RESV | MX_STAT);   // ViT block 0
+        MX_CASE(MX_D1 | MX_RESV | MX_STAT);                // ViT LN1 (x += dF) and LN2 (x += dO)
+        MX_CASE(MX_D1 | MX_RESV | MX_CLSONLY);             // ViT closing add of the CLS rows when x + dO is in the stream already
         default: iisan_set_error("layernorm768_mixed: operand set %d not instantiated", V); return IISAN_EBADSHAPE;
     }
 #undef MX_CASE
@@ -523,6 +543,76 @@ extern "C" int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_
         hipLaunchKernelGGL(cast16_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
     else
         hipLaunchKernelGGL(cast16_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+// ---- LayerNorm folded into the weights of the product that consumes it (Gemm16Args::rowstat) ----
+// LN(x) W^T + b = rstd (x Wf^T) + bf with Wf[n][k] = gamma[k] W[n][k] - (1/K) sum_j gamma[j] W[n][j] — CENTRED rows: sum_k x[k] Wf[n][k] =
+// sum_k (x[k] - mean(x)) gamma[k] W[n][k] for every x, so the product of the un-normalised row needs no mean correction — and
+// bf = b + W beta.  The fp16 rounding of Wf leaves a row sum d_n = sum_k (Wf16 - Wf) != 0 and with it an error mean(x) rstd d_n that
+// grows with |mean| / std of the row (CPU emulation: 1.7e-4 -> 5.1e-4 relative at |mean| = 3 std with round-to-nearest).  So the
+// rounding DIFFUSES its error along the row (each lane carries the error of an element into the next of its 24, the 32 lanes' last
+// carries are added to one element): |d_n| <= half an ulp of one weight, ~1e-5 of the ~4e-4 round-to-nearest leaves, at the price of
+// errors up to one ulp instead of half in the single weights.  The weights are frozen, but the ABI is stateless: folded once per
+// forward call (200 MB of traffic for ViT-B, ~40 us) into the workspace.
+// Half a wave per weight row (K = 768: three 8-element pieces per lane), 8 rows per workgroup, every job in one launch.
+struct LnFoldArgs { LnFoldJob j[32]; int32_t row0[33]; int32_t n; };
+
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(LnFoldArgs a) {
+    const int lane = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= a.row0[a.n]) return;
+    int ji = 0;
+    while (row >= a.row0[ji + 1]) ++ji;
+    const LnFoldJob& J = a.j[ji];
+    const int n = row - a.row0[ji];
+    const _Float16* w = (const _Float16*)J.W + (int64_t)n * 768;
+    _Float16* wf = (_Float16*)J.Wf + (int64_t)n * 768;
+    float v[3][8];
+    float cs = 0.f, bw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 8;
+        const h8 x = *(const h8*)(w + c);
+        const f4 g0 = *(const f4*)(J.g + c), g1 = *(const f4*)(J.g + c + 4), b0 = *(const f4*)(J.b + c), b1 = *(const f4*)(J.b + c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xe = (float)x[e];
+            v[i][e] = xe * (e < 4 ? g0[e] : g1[e - 4]);
+            cs += v[i][e];
+            bw += xe * (e < 4 ? b0[e] : b1[e - 4]);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { cs += __shfl_xor(cs, o, 64); bw += __shfl_xor(bw, o, 64); }
+    const float mu = cs * (1.0f / 768.0f);
+    h8 o16[3];
+    float carry = 0.f;                      // rounding error not yet given back: target - emitted, over the lane's elements so far
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = (v[i][e] - mu) + carry;
+            o16[i][e] = (_Float16)t;
+            carry = t - (float)o16[i][e];
+        }
+    float rest = carry;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
+    if (lane == 0) o16[0][0] = (_Float16)((float)o16[0][0] + rest);       // the lanes' last carries: into one element
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *(h8*)(wf + i * 256 + lane * 8) = o16[i];
+    if (lane == 0) J.bf[n] = (J.bias ? J.bias[n] : 0.f) + bw;
+}
+
+int launch_fold_ln_weights(const LnFoldJob* jobs, int n, hipStream_t s) {
+    IISAN_CHECK_SHAPE(n >= 0 && n <= 32, "fold_ln_weights: %d jobs (at most 32 per launch)", n);
+    if (n == 0) return IISAN_OK;
+    LnFoldArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) { a.j[i] = jobs[i]; a.row0[i + 1] = a.row0[i] + jobs[i].N; }
+    hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((unsigned)ceil_div((int64_t)a.row0[n], 8)), dim3(256), 0, s, a);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

@@ -108,9 +108,18 @@ def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
     vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda")
     bert = encoders.PackedBert(bw, weights.BERT_BASE, "cuda")
     sel = [0, 2, 4, 6, 8, 10, 12]
+    # round 5: at this size the ViT tower applies its LayerNorms in the epilogues of the QKV / FC1 products (gamma-folded, centred
+    # weights; `iisan_set_ln_fold`), which the 128x128 kernels do not do — a different rounding sequence, not a different kernel
+    # family.  So two production runs: LayerNorm images (the kernels alone differ: tight bound) and the default (bound = the
+    # decorrelated 16-bit operand noise, as between the fp32 and the mixed stream above).
+    try:
+        lib.iisan_set_ln_fold(0)
+        tc_img = vit.forward_taps(b.images, sel)
+    finally:
+        lib.iisan_set_ln_fold(1)
     tc = vit.forward_taps(b.images, sel)
     tt = bert.forward_taps(b.text, sel)
-    assert torch.isfinite(tc).all() and torch.isfinite(tt).all()
+    assert torch.isfinite(tc).all() and torch.isfinite(tt).all() and torch.isfinite(tc_img).all()
     try:
         lib.iisan_set_gemm16_variant(1)
         rc = vit.forward_taps(b.images, sel, chunk_items=8)
@@ -118,16 +127,22 @@ def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
     finally:
         lib.iisan_set_gemm16_variant(0)
     assert torch.equal(tc[:, 0], rc[:, 0]) and torch.equal(tt[:, 0], rt[:, 0])        # tap 0 involves no GEMM kernel choice
+    assert not torch.equal(tc, tc_img), "the default ViT run did not take the LayerNorm-in-the-epilogue route at production size"
     # (measured: the two kernel families agree BIT FOR BIT here — both walk K in ascending order into fp32 accumulators —
     # so the bound below is a ceiling, not the observed difference)
     for k in range(1, len(sel)):
         # two correct fp16-operand executions differ by accumulation order only: far inside the 1.5e-3 budget vs the reference
-        assert _rel(tc[:, k], rc[:, k]) < 4e-4, f"ViT tap {sel[k]}: {_rel(tc[:, k], rc[:, k]):.3e}"
+        assert _rel(tc_img[:, k], rc[:, k]) < 4e-4, f"ViT tap {sel[k]}: {_rel(tc_img[:, k], rc[:, k]):.3e}"
         assert _rel(tt[:, k], rt[:, k]) < 4e-4, f"BERT tap {sel[k]}: {_rel(tt[:, k], rt[:, k]):.3e}"
+        # (measured 7.8e-4 .. 1.05e-3 from tap 2 to tap 12: two roundings of different kinds — the image route rounds LayerNorm(x), the
+        #  epilogue route rounds the folded weights a second time — decorrelate to the sum of both noises; tools/lnfold_ab.py)
+        assert _rel(tc[:, k], rc[:, k]) < 1.5e-3, f"ViT tap {sel[k]} (LayerNorm in the epilogues): {_rel(tc[:, k], rc[:, k]):.3e}"
         # and no single slot is off (a mis-addressed tile would corrupt a few rows, not the norm)
+        per_i = (tc_img[:, k] - rc[:, k]).norm(dim=1) / rc[:, k].norm(dim=1)
         per_c = (tc[:, k] - rc[:, k]).norm(dim=1) / rc[:, k].norm(dim=1)
         per_t = (tt[:, k] - rt[:, k]).norm(dim=1) / rt[:, k].norm(dim=1)
-        assert per_c.max().item() < 2e-3 and per_t.max().item() < 2e-3, (sel[k], per_c.max().item(), per_t.max().item())
+        assert per_i.max().item() < 2e-3 and per_t.max().item() < 2e-3, (sel[k], per_i.max().item(), per_t.max().item())
+        assert per_c.max().item() < 4e-3, (sel[k], per_c.max().item())
 
 
 def test_small_config_taps_match_oracle():

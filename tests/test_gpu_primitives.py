@@ -129,6 +129,90 @@ def test_gemm16_h256_tile_walks_are_bit_identical(lib, shape):
         lib.iisan_set_gemm16_walk(-1, 0)
 
 
+def _ln_fold_case(M, N, K, row_mean, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(M, K, generator=g, device="cuda") * 0.8 + row_mean
+    x[:, 7] += 20.0; x[:, 300] -= 9.0                        # the "massive activation" channels of a ViT stream
+    x16 = _pad_rows(x.half())
+    gamma = 1.0 + 0.3 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.2 * torch.randn(K, generator=g, device="cuda")
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    b = torch.randn(N, generator=g, device="cuda")
+    xf = x16.float()
+    mean = xf.mean(1, keepdim=True)
+    rstd = torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-6)
+    ln32 = (xf - mean) * rstd * gamma + beta
+    return x16, gamma, beta, W, b, rstd.reshape(-1).contiguous(), ln32
+
+
+@pytest.mark.parametrize("row_mean", [0.3, 3.0])
+def test_layernorm_fold_of_the_weights_is_centred_and_sum_preserving(lib, row_mean):
+    """Round 5: `fold_ln_weights_kernel` (rowops.hip) — Wf[n] = fp16(gamma * W[n] - mean_k(gamma * W[n])), bias' = b + W beta.  Every
+    folded element within 1.5 ulp of its target, the ROW SUMS within one ulp of zero (plain rounding leaves ~20x that: the sum is what
+    multiplies the mean of an activation row), and LN(x) W^T + b == rstd * (x Wf^T) + bias' to fp16-operand accuracy in fp64
+    arithmetic — also for rows whose mean is several standard deviations."""
+    N, K = 2304, 768
+    x16, gamma, beta, W, b, rstd, ln32 = _ln_fold_case(512, N, K, row_mean, 11)
+    Wf = torch.empty_like(W); bf = torch.empty(N, device="cuda")
+    _lib.check(lib.iisan_fold_ln_weights(W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
+    torch.cuda.synchronize()
+    Wg = W.double() * gamma.double()
+    Wc = Wg - Wg.mean(1, keepdim=True)
+    ulp = 2.0 ** -10 * Wc.abs().clamp_min(2.0 ** -14)                     # fp16 spacing at the element's magnitude (upper bound)
+    assert ((Wf.double() - Wc).abs() <= 1.5 * ulp).all()
+    sums = Wf.double().sum(1).abs()
+    plain = Wc.half().double().sum(1).abs()
+    assert sums.max().item() <= 2.0 ** -10 * Wc.abs().max().item(), sums.max().item()
+    assert sums.max().item() < 0.2 * plain.max().item(), (sums.max().item(), plain.max().item())
+    assert (bf.double() - (b.double() + W.double() @ beta.double())).abs().max().item() < 1e-5
+    ref = ln32.double() @ W.double().t() + b.double()
+    alg = rstd.double()[:, None] * (x16.double() @ Wf.double().t()) + bf.double()
+    img = ln32.half().double() @ W.double().t() + b.double()
+    e_alg = ((alg - ref).norm() / ref.norm()).item()
+    e_img = ((img - ref).norm() / ref.norm()).item()
+    assert e_alg < 1.5 * e_img and e_alg < 4e-4, (e_alg, e_img)
+
+
+@pytest.mark.parametrize("case", [("qkv", 4, 2304, 197 * 335), ("fc1", 1, 3072, 277376), ("fc1", 1, 3072, 1500)])
+def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
+    """Round 5: `gemm16_h256_kernel<.., LNA = true>` — LayerNorm applied by the epilogue of the product that consumes it: A = the
+    un-normalised fp16 rows, W = the folded weights, one rstd per row (brought in per tile by LDS-DMA), out = rstd * acc + bias'.
+    EVERY element is held to fp32 arithmetic (GELU) / to the same kernel on the materialised LayerNorm image (head-major QKV) over
+    three launches that must agree bit for bit: the first version of this epilogue let the compiler broadcast the statistic by
+    op_sel and lost a product in the last 16 lanes of a wave a few thousand times per 8.5e8 outputs, different ones every run."""
+    name, mode, N, M = case
+    K, S = 768, 197
+    x16, gamma, beta, W, b, rstd, ln32 = _ln_fold_case(M, N, K, 0.3, N + M)
+    Wf = torch.empty_like(W); bf = torch.empty(N, device="cuda")
+    _lib.check(lib.iisan_fold_ln_weights(W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
+    Mp = x16.shape[0]
+    outs = []
+    try:
+        lib.iisan_set_gemm16_variant(4)
+        for rep in range(3):
+            out = torch.zeros(Mp, N, dtype=torch.float16, device="cuda")
+            _lib.check(lib.iisan_gemm16_lna(mode, x16.data_ptr(), Wf.data_ptr(), bf.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, N, K, S, _stream()), "gemm16_lna")
+            outs.append(out)
+        img = torch.zeros(Mp, N, dtype=torch.float16, device="cuda")
+        ln16 = ln32.half().contiguous()
+        _lib.check(lib.iisan_gemm16_lna(mode, ln16.data_ptr(), W.data_ptr(), b.data_ptr(), img.data_ptr(), None, M, N, K, S, _stream()), "gemm16 (image)")
+    finally:
+        lib.iisan_set_gemm16_variant(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    worst = 0.0
+    for r0 in range(0, M, 32768):
+        r1 = min(M, r0 + 32768)
+        if mode == 1:
+            want = torch.nn.functional.gelu(ln32[r0:r1] @ W.float().t() + b)
+        else:
+            want = img[r0:r1].float()
+        worst = max(worst, (outs[0][r0:r1].float() - want).abs().max().item())
+    assert worst < 0.02, worst          # outputs are O(1..10); a lost product is O(0.1..1), 16-bit rounding of both sides 8e-3
+    if mode == 1:
+        assert not outs[0][M:].any()    # rows beyond M are not written
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 def test_layernorm768_vs_torch(lib, dt):
     g = torch.Generator().manual_seed(3)
