@@ -94,6 +94,8 @@ EXTRA_SIGNATURES = {
     "iisan_gemm16_lna": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_fold_ln_weights": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "iisan_set_ln_fold": (None, [i32]),
+    "iisan_gemm16_stream": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "iisan_stream_stats_finalize": (i32, [vp, i32, i64, vp, vp, vp, f32, i64, i32, vp]),
     "iisan_set_gemm16_desync": (None, [i32]),
     "iisan_set_gemm16_h256": (None, [i32]),
     "iisan_set_attn_debug": (None, [i32]),

@@ -252,18 +252,25 @@ struct Gemm16Args {
     //     LN(x) W^T + b  =  rstd_m * acc[m][n] + bias'[n],     bias' = b + W beta (in `bias`)
     // rowstat = [Mpad] fp32: rstd of every row of A; null = plain product
     const float* rowstat;
+    float* rowpart;     // EPI_STREAM16: [N / 64][Mpad][2] partial row statistics (Mpad = M rounded up to 256)
     // EPI_F32 (split-operand GEMM of the trainable path, split.hip): out fp32 = acc * inv_a[0] * inv_b[0] (+ bias) (+ resid)
     const float* inv_a; const float* inv_b;     // device scalars (reciprocal operand scales), null = 1
     int32_t atomic;     // 1: accumulate into out with fp32 atomics (bench knob only: ~20 G atomics/s chip-wide, far too slow)
     int64_t split_stride;   // EPI_F32 split-K: K-split y writes its partial product to out + y*split_stride (bias / resid: reducer)
     const int32_t* skip_last_third;   // EPI_F32: device flag; when it reads 0 the last third of K is all zeros and is not multiplied
 };
-enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5, EPI_PATCH16 = 6 };
+enum { EPI_OUT16 = 0, EPI_GELU16 = 1, EPI_RESID32 = 2, EPI_PATCH32 = 3, EPI_QKVH16 = 4, EPI_F32 = 5, EPI_PATCH16 = 6, EPI_STREAM16 = 7 };
+// EPI_STREAM16 (gemm16_h256 only, fp16, N = ldo): the residual add of a pre-LN tower in the epilogue — out IS the fp16 stream x [Mpad, N],
+// read and written in place: x[m] = fp16(x[m] + acc[m] + bias), and `rowpart` [N / 64][Mpad] (sum, sum of squares) receives every
+// row's statistics over each 64-column slice (reduced in a fixed order by stream_stats_finalize, rowops.hip).  Rows m = item * qkv_S
+// (the CLS rows, whose stream is the fp32 `xc` of the executor) receive the DELTA fp16(acc + bias) alone: the finalize step adds it to
+// their fp32 stream and writes the rounded sum back.
 // EPI_PATCH16: 16-bit output, patch row m of image m / P -> token row m + m / P + 1 (bias added; the position embedding is added by
 // the LayerNorm kernel that reads the rows — rowops.hip, MX_POSROW)
 // EPI_QKVH16: 16-bit output scattered head-major, out[item][head][q|k|v][token][64] (item = m / S): every (item, head)
 // slice the attention kernel streams is then one contiguous block instead of 128-byte pieces at a 4.6 KB stride.
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s);
+bool gemm16_runs_h256(int dtype16, int mode, const Gemm16Args& a);       // gemm16.hip: would this product run on gemm16_h256 (EPI_STREAM16 exists only there)?
 bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a);   // gemm16.hip: would this product run on the kernel that applies LayerNorm in its epilogue?
 int launch_layernorm768(int dtype16, const float* x, const float* g, const float* b, float eps, void* out16,
                         float* out32, int64_t rows, hipStream_t s);
@@ -287,6 +294,10 @@ int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, f
 // with sum_k Wf[n][k] = 0 to the last bit that matters, bf[n] = bias[n] + sum_k beta[k] W[n][k]; K = 768, fp16 weights.  Up to 32 jobs in one launch.
 struct LnFoldJob { const void* W; const float* bias; const float* g; const float* b; void* Wf; float* bf; int32_t N; };
 int launch_fold_ln_weights(const LnFoldJob* jobs, int n, hipStream_t s);
+// after an EPI_STREAM16 product: rstat[m] = rstd of row m from the `nslots` partial sums of rowpart [nslots][Mpad][2]; the CLS rows
+// (m = item * Ttok): xc[item] += the fp16 delta the product left in x16[m]; x16[m] = fp16(xc[item]); rstat[m] from the rounded row
+int launch_stream_stats_finalize(const float* rowpart, int nslots, int64_t Mpad, void* x16, float* xc, float* rstat, float eps,
+                                 int64_t items, int Ttok, hipStream_t s);
 int launch_attention16(int dtype16, const void* qkv, const float* key_bias, void* ctx, int64_t items, int S,
                        int heads, hipStream_t s);
 // CLS query only: ctx_cls [items, heads*64] (last executed encoder block)

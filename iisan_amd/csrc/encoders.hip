@@ -32,6 +32,7 @@ struct EncBufs {
     void* Wf;       // [layers][3D + F, D] fp16: gamma-folded, centred QKV and FC1 weights
     float* Bf;      // [layers][3D + F]: folded biases
     float* RS;      // [Tp]: rstd of every row of the stream
+    float* RP;      // [D / 64][Tp][2]: per-slice row sums of the products that add into the stream (EPI_STREAM16)
 };
 
 // 1 = keep the whole residual stream in fp32 (rounds 1-3); 0 (default) = fp32 for the CLS rows, fp16 for the others (rowops.hip).
@@ -40,8 +41,10 @@ int g_resid32 = 0;
 // 1 (default): the pre-LN tower (ViT) with fp16 operands and the mixed stream never materialises LayerNorm(x): the add kernels write
 // the stream and rstd per row, the QKV / FC1 products read the stream itself against gamma-folded, centred weights and apply
 // rstd in their epilogues (Gemm16Args::rowstat) — 12 instead of 16 bytes per token row and block in the HBM-bound kernels.
+// 2 (default): ... and no add kernel either: the O / FC2 products add into the fp16 stream in their epilogues (EPI_STREAM16) and leave
+// per-slice row sums, a small kernel turns those into rstd and folds the CLS rows' deltas into their fp32 stream.
 // 0: the LayerNorm image of rounds 1-4.  Bench / test knob.
-int g_ln_fold = 1;
+int g_ln_fold = 2;
 
 size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems, int fold_layers = 0) {
     const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
@@ -57,11 +60,12 @@ size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int 
     b.D16 = c.take<uint16_t>((size_t)Tp * D);
     b.D16b = c.take<uint16_t>((size_t)Tp * D);
     b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
-    b.Wf = nullptr; b.Bf = nullptr; b.RS = nullptr;
+    b.Wf = nullptr; b.Bf = nullptr; b.RS = nullptr; b.RP = nullptr;
     if (fold_layers > 0) {
         b.Wf = c.take<uint16_t>((size_t)fold_layers * (3 * D + F) * D);
         b.Bf = c.take<float>((size_t)fold_layers * (3 * D + F));
         b.RS = c.take<float>((size_t)Tp);
+        b.RP = c.take<float>((size_t)(D / 64) * Tp * 2);
     }
     return c.off;
 }
@@ -195,6 +199,22 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
               gemm16_takes_rowstat(dt, EPI_GELU16, gemm_args(EPI_GELU16, nullptr, D, nullptr, nullptr, nullptr, F, tok)) &&
               (full_blocks || gemm16_takes_rowstat(dt, EPI_QKVH16, gemm_args(EPI_QKVH16, nullptr, D, nullptr, nullptr, nullptr, 2 * D, tok, T, w->heads, 1)));
     }
+    // ... and the residual adds in the epilogues of the O / FC2 products
+    bool lnb = lna && g_ln_fold >= 2;
+    for (int64_t mc : {Mc, M % Mc == 0 ? Mc : M % Mc}) {
+        const int64_t tok = mc * T;
+        Gemm16Args o = gemm_args(EPI_STREAM16, nullptr, D, nullptr, nullptr, nullptr, D, tok, T), f = gemm_args(EPI_STREAM16, nullptr, F, nullptr, nullptr, nullptr, D, tok, T);
+        o.rowpart = f.rowpart = b.RP;
+        lnb = lnb && gemm16_runs_h256(dt, EPI_STREAM16, o) && gemm16_runs_h256(dt, EPI_STREAM16, f);
+    }
+    // x += A W^T + bias in the stream (fp16 rows in place, the CLS rows' fp32 stream through the finalize step); rstd of the new rows
+    auto gemm_stream = [&](const void* A, int K, const void* W, const float* bias, int64_t mc) {
+        const int64_t tok = mc * T;
+        Gemm16Args a = gemm_args(EPI_STREAM16, A, K, W, bias, b.X16, D, tok, T);
+        a.rowpart = b.RP;
+        IISAN_TRY(launch_gemm16(dt, EPI_STREAM16, a, s));
+        return launch_stream_stats_finalize(b.RP, D / 64, ceil_div(tok, 256) * 256, b.X16, b.Xc, b.RS, w->eps, mc, T, s);
+    };
     const size_t fold_w = (size_t)(3 * D + F) * D;          // elements of one layer's folded weights
     auto Wf_qkv = [&](int l) { return (char*)b.Wf + (size_t)l * fold_w * 2; };
     auto Wf_fc1 = [&](int l) { return Wf_qkv(l) + (size_t)3 * D * D * 2; };
@@ -247,7 +267,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
                 // (x + dO is in the stream already: this block's predecessor wrote it in its LN2 step)
                 if (l == 0)
                     IISAN_TRY(launch_layernorm768_mixed(dt, MX_SRC32 | MX_POSROW | MX_ADD_STAT, w->pos_emb, b.X16, b.Xc, b.D16b, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s, b.RS));
-                else
+                else if (!lnb)       // (lnb: the FC2 product of block l - 1 added into the stream and left its statistics)
                     IISAN_TRY(launch_layernorm768_mixed(dt, MX_ADD_STAT, nullptr, b.X16, b.Xc, pend_f, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s, b.RS));
             } else if (!mixed)
                 IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, L.ln1_w, L.ln1_b, w->eps, pend_o ? b.X : nullptr, b.H, nullptr, tok, s));
@@ -258,7 +278,13 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
             pend_o = pend_f = nullptr;
             k = tap_index(tap_layers, n_taps, l);
             if (k >= 0 && l > 0) IISAN_TRY(tap(k));
-            if (lna && (l + 1 < live || full_blocks)) {
+            if (lnb && (l + 1 < live || full_blocks)) {
+                IISAN_TRY(gemm_ln(dt, EPI_QKVH16, b.X16, D, Wf_qkv(l), bf_qkv(l), b.RS, b.QKV, 3 * D, tok, s, T, w->heads));
+                IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
+                IISAN_TRY(gemm_stream(b.H, D, L.o_w, L.o_b, mc));
+                IISAN_TRY(gemm_ln(dt, EPI_GELU16, b.X16, D, Wf_fc1(l), bf_fc1(l), b.RS, b.F1, F, tok, s));
+                IISAN_TRY(gemm_stream(b.F1, F, L.fc2_w, L.fc2_b, mc));
+            } else if (lna && (l + 1 < live || full_blocks)) {
                 IISAN_TRY(gemm_ln(dt, EPI_QKVH16, b.X16, D, Wf_qkv(l), bf_qkv(l), b.RS, b.QKV, 3 * D, tok, s, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, nullptr, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
@@ -308,7 +334,8 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         if (full_blocks) {
             k = tap_index(tap_layers, n_taps, w->layers);
             if (k >= 0) {
-                if (lna)        // x + dO is in the stream: the CLS rows take dF
+                if (lnb) {}     // the stream is hidden state `layers` already
+                else if (lna)   // x + dO is in the stream: the CLS rows take dF
                     IISAN_TRY(launch_layernorm768_mixed(dt, MX_D1 | MX_RESV | MX_CLSONLY, nullptr, b.X16, b.Xc, pend_f, nullptr, nullptr, nullptr, w->eps, nullptr, mc, T, s));
                 else if (!mixed)
                     IISAN_TRY(launch_add2_layernorm768(dt, b.X, pend_o, pend_f, nullptr, nullptr, w->eps, b.X, nullptr, nullptr, tok, s));

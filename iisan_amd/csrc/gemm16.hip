@@ -277,6 +277,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(mode != EPI_PATCH32 || (a.patch_P > 0 && a.pos), "gemm16: patch mode needs P and pos");
     IISAN_CHECK_SHAPE(mode != EPI_PATCH16 || a.patch_P > 0, "gemm16: patch mode needs P");
     IISAN_CHECK_SHAPE(mode != EPI_RESID32 || a.resid, "gemm16: residual mode needs resid");
+    IISAN_CHECK_SHAPE(mode != EPI_STREAM16 || (a.rowpart && a.qkv_S > 0 && a.ldo == a.N), "gemm16: stream mode needs the row-sum buffer, S and ldo == N");
     IISAN_CHECK_SHAPE(mode != EPI_QKVH16 || (a.qkv_S > 0 && a.qkv_heads > 0 && a.qkv_which0 >= 0 && a.qkv_which0 <= 2 && a.N == (3 - a.qkv_which0) * 64 * a.qkv_heads),
                       "gemm16: head-major QKV mode needs S, heads and N == 3*64*heads");
     const bool timed = iisan_timing_on(s);
@@ -297,6 +298,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
         if (timed) iisan_timing_post(s);
         return rc;
     }
+    IISAN_CHECK_SHAPE(mode != EPI_STREAM16, "gemm16: the stream epilogue runs on gemm16_h256 only (M=%lld N=%d K=%d, variant %d)", (long long)a.M, a.N, a.K, var);
     IISAN_CHECK_SHAPE(!a.rowstat, "gemm16: a product with LayerNorm row statistics runs on gemm16_h256 only (mode %d, M=%lld N=%d K=%d, variant %d)",
                       mode, (long long)a.M, a.N, a.K, var);
     // the staggered kernel without the half-slot boundary: variant 3 (the race-screen reference of gemm16_h256) and the shapes
@@ -324,6 +326,28 @@ bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a) {
     if (!b.rowstat) b.rowstat = &dummy;
     return dtype16 == IISAN_F16 && big && (var == 4 || (g_auto_staggered && g_auto_h256)) && a.N % BN == 0 && a.K % BK == 0 &&
            gemm16_h256_applicable(mode, b);
+}
+
+// ... or on gemm16_h256 at all (EPI_STREAM16 exists only there)
+bool gemm16_runs_h256(int dtype16, int mode, const Gemm16Args& a) {
+    const int var = g_variant & 0xff;
+    const bool big = var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
+    return (mode != EPI_STREAM16 || dtype16 == IISAN_F16) && big && (var == 4 || (g_auto_staggered && g_auto_h256)) && a.N % BN == 0 &&
+           a.K % BK == 0 && gemm16_h256_applicable(mode, a);
+}
+
+// bench / test entry: x += A W^T + bias in the fp16 stream x [Mpad, N] (in place), per-slice row sums into rowpart [N / 64][Mpad][2]
+extern "C" int iisan_gemm16_stream(const void* A, const void* W, const float* bias, void* x16, float* rowpart, int64_t M, int32_t N,
+                                   int32_t K, int32_t S, void* stream) {
+    Gemm16Args a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = x16; a.rowpart = rowpart; a.qkv_S = S;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N;
+    return launch_gemm16(IISAN_F16, EPI_STREAM16, a, (hipStream_t)stream);
+}
+
+extern "C" int iisan_stream_stats_finalize(const float* rowpart, int32_t nslots, int64_t Mpad, void* x16, float* xc, float* rstat, float eps,
+                                           int64_t items, int32_t Ttok, void* stream) {
+    return launch_stream_stats_finalize(rowpart, nslots, Mpad, x16, xc, rstat, eps, items, Ttok, (hipStream_t)stream);
 }
 
 // bench / test entry (not in the product ABI): LN(x) W^T + b with the LayerNorm applied in the epilogue — A = x [M, K] fp16,

@@ -79,6 +79,8 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
         S256_FENCE();                                                                              \
     } while (0)
 #define S256_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0) */
+// the stores of a half-epilogue that may stay in flight over the wait at the end of its slot: 8 per wave, 9 with the row statistics
+#define S256_VMCNT_EPI() do { if constexpr (EPI == EPI_STREAM16) S256_VMCNT(9); else S256_VMCNT(8); } while (0)
 
 template <typename T, int EPI, bool LNA>
 __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         asm volatile("" : "+v"(l2));
         const int frow = l2 & 31, fh = l2 >> 5;
         const bool full = (int64_t)(tm + 1) * SBM <= p.M;
-        stores8 = full && !(p.debug & (1 | 32));
+        stores8 = full && !(p.debug & (1 | 32));        // (EPI_STREAM16: one more, the row statistics — S256_VMCNT_EPI)
         const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
         const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
         if (!(p.debug & 1)) {
@@ -402,11 +404,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     lane_off = (uint32_t)(frow * p.ldo * 2 + fh * 32);
                 }
                 f4 bbv[4];         // the lane's 16 bias values of column block ni (the same for every 32-row block)
+                // EPI_STREAM16: the lane's 16 old stream values of a block (the same 32 bytes the block's two stores overwrite), requested
+                // one block ahead of their use (all four blocks ahead: 51 registers spilled), and the row sums of the lane's two rows
+                V8 xold[4][2];
+                // (the four blocks' sums wait in a wave-private LDS row — 2 KiB per wave behind the bias — instead of four registers)
+                f2* sSum = (f2*)(sBias + 1024) + (wave * 4) * 64 + lane;
+                auto load_old = [&](int b) {
+                    const int mi = 2 * half + (b & 1), ni = b >> 1;
+                    const char* ip = (const char*)p.out + ((int64_t)(row0 + mi * 32) * p.ldo + col0 + ni * 32) * 2 + lane_off;
+                    xold[b][0] = *(const V8*)ip;
+                    xold[b][1] = *(const V8*)(ip + 16);
+                };
+                constexpr bool PF_STREAM = true;
+                if constexpr (EPI == EPI_STREAM16 && PF_STREAM) { load_old(0); S256_FENCE(); }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int mi = 2 * half + (b & 1), ni = b >> 1;
+                    if constexpr (EPI == EPI_STREAM16) {
+                        if (PF_STREAM ? b < 3 : true) load_old(PF_STREAM ? b + 1 : b);
+                        S256_FENCE();
+                    }
                     f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
-                    if (!LNA && (b & 1) == 0) {
+                    V8 o0, o1;
+                    if (!LNA && EPI != EPI_STREAM16 && (b & 1) == 0) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
                     }
@@ -432,6 +452,34 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                                 g[4 * hf + k] = __builtin_elementwise_fma((f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]}, sx,
                                                                           k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
                         }
+                    } else if constexpr (EPI == EPI_STREAM16) {
+                        // x += acc + bias, eight columns at a time (bias re-read from LDS per block as in the LNA epilogue: registers); a CLS
+                        // row (m = item * S, its stream is the executor's fp32 xc) receives the delta alone
+                        const uint32_t m = (uint32_t)(row0 + mi * 32 + frow);
+                        const bool cls = m - __umulhi(m, qkv_magic) * (uint32_t)p.qkv_S == 0u;
+                        f2 s2 = (f2){0.f, 0.f}, q2 = (f2){0.f, 0.f};        // even / odd columns apart: v_pk_add_f32 / v_pk_fma_f32
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const f4 b0 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf), b1 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf + 4);
+                            // (the launder pins the conversions HERE: left alone they are hoisted above the full / ragged branch, all 16 of
+                            //  a block at once, into a slot that has ~30 free registers: 39-67 spilled)
+                            V8 xo = xold[b][hf];
+                            asm volatile("" : "+v"(xo));
+                            if (cls) xo = (V8)(_Float16)0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const f2 x2 = (f2){(float)xo[2 * k], (float)xo[2 * k + 1]};
+                                f2 t = (f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]} + (k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
+                                t += x2;
+                                s2 += t;
+                                q2 = __builtin_elementwise_fma(t, t, q2);
+                                // converted at once: the eight sums of a block never sit in registers together
+                                if (hf == 0) { o0[2 * k] = T::from_f32(t[0]); o0[2 * k + 1] = T::from_f32(t[1]); }
+                                else { o1[2 * k] = T::from_f32(t[0]); o1[2 * k + 1] = T::from_f32(t[1]); }
+                            }
+                            S256_FENCE();
+                        }
+                        sSum[b * 64] = (f2){s2[0] + s2[1], q2[0] + q2[1]};
                     } else {
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
@@ -440,11 +488,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live
                     //  across this slot, and spilled)
                     if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
-                    V8 o0, o1;
+                    if constexpr (EPI != EPI_STREAM16) {
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
-                        o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
+                        for (int e = 0; e < 8; e += 2) {
+                            o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
+                            o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
+                        }
                     }
 #ifdef S256_TIMELINE
                     if (p.debug & 32) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
@@ -478,6 +527,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                             *(V8*)(op + 16) = o1;
                         }
                     }
+                }
+                if constexpr (EPI == EPI_STREAM16) {
+                    // the lane's two rows over this wave's 64 columns: lanes l and l ^ 32 hold the two 16-column halves of both.  One
+                    // v_permlane32_swap per statistic leaves row block 2 half in lanes 0..31 and row block 2 half + 1 in lanes 32..63,
+                    // one 8-byte store per lane: slice-major [N / 64][Mpad] so that a wave writes two 256-byte runs
+                    // (inline asm: this hipcc's __builtin_amdgcn_permlane32_swap returns the first register twice — `v_add_f32 v1, v1, v1`
+                    //  behind the swap — so the builtin's sum is 2 x one half; the swap exchanges a[32..63] with b[0..31] in place)
+                    auto both = [](float a, float b) {
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                        return a + b;
+                    };
+                    const f2 a0 = sSum[0], a1 = sSum[64], a2 = sSum[128], a3 = sSum[192];       // blocks (mi, ni) = (0,0) (1,0) (0,1) (1,1)
+                    const f2 st = (f2){both(a0[0] + a2[0], a1[0] + a3[0]), both(a0[1] + a2[1], a1[1] + a3[1])};
+                    const int64_t slot = (int64_t)(col0 >> 6) * ((int64_t)tiles_m * SBM);
+                    *(f2*)(p.rowpart + (slot + row0 + (2 * half + fh) * 32 + frow) * 2) = st;
                 }
             };
             if (full) run(std::true_type{}); else run(std::false_type{});
@@ -580,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             read_hi(s);
             S256_LGKM0();
             // the 8 pieces of Mlo (and, older, the 8 stores of the lo half); the 8 stores just issued stay in flight
-            if (s > 0 && stores8) S256_VMCNT(8); else S256_VMCNT(0);
+            if (s > 0 && stores8) S256_VMCNT_EPI(); else S256_VMCNT(0);
             stamp();
             S256_BARRIER();
             stamp();
@@ -618,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             epilogue(cur_tm, cur_tn, 0, ti & 1);
             read_hi(s);
             S256_LGKM0();
-            if (stores8) S256_VMCNT(8); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
+            if (stores8) S256_VMCNT_EPI(); else S256_VMCNT(0);      // the 4 pieces of Mlo; the 8 stores just issued stay in flight
             stamp();
             S256_BARRIER();
             stamp();
@@ -661,7 +725,7 @@ int launch_epi(const Gemm16Args& a, hipStream_t s) {
     int grid = (int)(ntiles < cus ? ntiles : cus);
     grid = (grid + 7) / 8 * 8;
     // EPI_QKVH16: item = row / S as one v_mul_hi_u32 by floor(2^32 / S) + 1 — exact while row * S < 2^32 (gemm16_h256_applicable)
-    const int div = EPI == EPI_PATCH16 ? a.patch_P : a.qkv_S;
+    const int div = EPI == EPI_PATCH16 ? a.patch_P : a.qkv_S;       // (EPI_STREAM16: S, for the CLS-row test)
     const uint32_t magic = div > 0 ? (uint32_t)((1ull << 32) / (uint64_t)div) + 1u : 0u;
     Gemm16Args b = a;
     // the panel walk needs at least one row tile per XCD slab and a panel narrower than the tile row
@@ -687,6 +751,9 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
         case EPI_GELU16: return launch_epi<T, EPI_GELU16>(a, s);
         case EPI_QKVH16: return launch_epi<T, EPI_QKVH16>(a, s);
         case EPI_PATCH16: return launch_epi<T, EPI_PATCH16>(a, s);
+        case EPI_STREAM16:
+            if constexpr (std::is_same<T, F16>::value) return launch_epi<F16, EPI_STREAM16>(a, s);
+            iisan_set_error("gemm16_h256: the stream epilogue needs fp16 operands"); return IISAN_EBADSHAPE;
         default: iisan_set_error("gemm16_h256: epilogue mode %d not supported", mode); return IISAN_EBADSHAPE;
     }
 }
@@ -694,7 +761,7 @@ int launch_t(int mode, const Gemm16Args& a, hipStream_t s) {
 }  // namespace
 
 bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
-    if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16 || mode == EPI_PATCH16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
+    if (!((mode == EPI_OUT16 || mode == EPI_GELU16 || mode == EPI_QKVH16 || mode == EPI_PATCH16 || mode == EPI_STREAM16) && a.N % SBN == 0 && a.N * 4 <= STG_BIAS_BYTES && a.K % SBK == 0 &&
           a.K / SBK >= 2 && (int64_t)a.lda * 2 * SBM < (1ll << 31) && (int64_t)a.ldw * 2 * SBN < (1ll << 31)))
         return false;
     if (a.rowstat && !((mode == EPI_QKVH16 || mode == EPI_GELU16) && a.N <= LNA_MAX_N)) return false;
@@ -704,6 +771,8 @@ bool gemm16_h256_applicable(int mode, const Gemm16Args& a) {
                                  // K/V-only product of the CLS-pruned last block still addresses the full tensor) — ADVICE r3: the bound
                                  // used (3 - which0) and let row counts in [932k, 1.40M) wrap at 12 heads
         return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && rows * 3 * (int64_t)a.qkv_heads * 128 + 128 < (1ll << 32);
+    if (mode == EPI_STREAM16)    // exact reciprocal division of the row index; in place: the output row stride is N
+        return a.qkv_S > 0 && rows * a.qkv_S < (1ll << 32) && a.rowpart && a.ldo == a.N && a.N <= 1024 && (int64_t)a.ldo * 2 * 16 + 64 < (1ll << 31);
     if (mode == EPI_PATCH16)     // 32-bit byte offsets of the remapped rows, exact reciprocal division
         return a.patch_P > 0 && rows * a.patch_P < (1ll << 32) && (rows + rows / a.patch_P + 2) * (int64_t)a.ldo * 2 < (1ll << 32);
     return (int64_t)a.ldo * 2 * 16 + 64 < (1ll << 31);       // the 32-bit lane offset of a 16-row store

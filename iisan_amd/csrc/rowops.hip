@@ -616,3 +616,75 @@ int launch_fold_ln_weights(const LnFoldJob* jobs, int n, hipStream_t s) {
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
+
+// ---- after an EPI_STREAM16 product (gemm16_h256.hip): the rows' rstd from the per-slice partial sums, and the CLS rows ----
+// Blocks [0, ceil(rows / 256)): one thread per row sums the `nslots` (sum, sum of squares) pairs in slice order — a fixed order, so the
+// statistics are bit-reproducible — and writes rstd; single-pass variance in fp32 (E[x^2] - mean^2: the stream's rows have |mean| well
+// under their spread; relative error ~1e-7 (1 + mean^2 / var)).  CLS rows are skipped there and done by the blocks behind: half a wave
+// per item adds the fp16 delta the product left in the stream's CLS slot to the item's fp32 stream, writes the rounded sum back (the
+// next product's A operand) and the rstd of the ROUNDED row, two-pass.
+__global__ __launch_bounds__(256) void stream_stats_finalize_kernel(const f2* __restrict__ part, int nslots, int64_t Mpad, _Float16* x16,
+                                                                    float* xc, float* __restrict__ rstat, float eps, int64_t items,
+                                                                    int Ttok, unsigned row_blocks) {
+    const int64_t rows = items * Ttok;
+    if (blockIdx.x < row_blocks) {
+        const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (row >= rows || row % Ttok == 0) return;
+        float s = 0.f, q = 0.f;
+        for (int j = 0; j < nslots; ++j) {
+            const f2 v = part[(int64_t)j * Mpad + row];
+            s += v[0]; q += v[1];
+        }
+        const float mean = s * (1.0f / 768.0f);
+        const float var = fmaxf(q * (1.0f / 768.0f) - mean * mean, 0.f);
+        rstat[row] = rsqrtf(var + eps);
+        return;
+    }
+    const int lane = threadIdx.x & 31;
+    const int64_t item = (int64_t)(blockIdx.x - row_blocks) * 8 + (threadIdx.x >> 5);
+    if (item >= items) return;
+    const int64_t row = item * Ttok;
+    float v[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 8;
+        const h8 d = *(const h8*)(x16 + row * 768 + c);
+        const f4 a = *(const f4*)(xc + item * 768 + c), b = *(const f4*)(xc + item * 768 + c + 4);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] = (e < 4 ? a[e] : b[e - 4]) + (float)d[e];
+            o[e] = (_Float16)v[i][e];
+        }
+        *(f4*)(xc + item * 768 + c) = (f4){v[i][0], v[i][1], v[i][2], v[i][3]};
+        *(f4*)(xc + item * 768 + c + 4) = (f4){v[i][4], v[i][5], v[i][6], v[i][7]};
+        *(h8*)(x16 + row * 768 + c) = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] = (float)o[e]; s += v[i][e]; }
+    }
+    auto sum32 = [](float t) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    const float mean = sum32(s) * (1.0f / 768.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(sum32(q) * (1.0f / 768.0f) + eps);
+    if (lane == 0) rstat[row] = rstd;
+}
+
+int launch_stream_stats_finalize(const float* rowpart, int nslots, int64_t Mpad, void* x16, float* xc, float* rstat, float eps,
+                                 int64_t items, int Ttok, hipStream_t s) {
+    if (items <= 0) return IISAN_OK;
+    const int64_t row_blocks = ceil_div(items * Ttok, 256), cls_blocks = ceil_div(items, 8);
+    IISAN_CHECK_SHAPE(row_blocks + cls_blocks < (1ll << 31), "stream_stats_finalize: grid too large");
+    hipLaunchKernelGGL(stream_stats_finalize_kernel, dim3((unsigned)(row_blocks + cls_blocks)), dim3(256), 0, s, (const f2*)rowpart, nslots, Mpad,
+                       (_Float16*)x16, xc, rstat, eps, items, Ttok, (unsigned)row_blocks);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}

@@ -24,14 +24,14 @@ res = {}
 lib.iisan_set_gemm16_variant(4)
 for fb in (1, 0):
     lib.iisan_set_full_blocks(fb)
-    for fold in (0, 1):
+    for fold in (0, 1, 2):
         lib.iisan_set_ln_fold(fold)
         res[(fb, fold)] = vit.forward_taps(b.images.cuda(), list(range(13))).cpu()
-lib.iisan_set_gemm16_variant(0); lib.iisan_set_ln_fold(1); lib.iisan_set_full_blocks(0)
-print("relative Frobenius error of ViT tap l vs the reference golden  [every block on every token: images, epilogue | CLS-only last block: images, epilogue | epilogue vs images]")
+lib.iisan_set_gemm16_variant(0); lib.iisan_set_ln_fold(2); lib.iisan_set_full_blocks(0)
+print("relative Frobenius error of ViT tap l vs the reference golden  [every block on every token: images (0), LN in the epilogues (1), + adds in the epilogues (2) | CLS-only last block: 0, 1, 2 | 2 vs 0]")
 for l in range(13):
-    print(f"  tap {l:2d}: {rel(res[(1, 0)][:, l], ref_c[:, l]):.3e} {rel(res[(1, 1)][:, l], ref_c[:, l]):.3e} | {rel(res[(0, 0)][:, l], ref_c[:, l]):.3e} {rel(res[(0, 1)][:, l], ref_c[:, l]):.3e} | "
-          f"{rel(res[(1, 1)][:, l], res[(1, 0)][:, l]):.3e}", flush=True)
+    print(f"  tap {l:2d}: " + " ".join(f"{rel(res[(1, f)][:, l], ref_c[:, l]):.3e}" for f in (0, 1, 2)) + " | " + " ".join(f"{rel(res[(0, f)][:, l], ref_c[:, l]):.3e}" for f in (0, 1, 2)) +
+          f" | {rel(res[(1, 2)][:, l], res[(1, 0)][:, l]):.3e}", flush=True)
 
 vw2 = weights.make_vit_weights()
 bb = synth.scientific_batch(bs=128, seed=12345, device="cuda", images_on_device=True)
@@ -40,7 +40,7 @@ sel = [0, 2, 4, 6, 8, 10, 12]
 lib.iisan_set_full_blocks(1)
 taps = {}
 for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    for fold in (0, 1):
+    for fold in (0, 1, 2):
         lib.iisan_set_ln_fold(fold)
         t = vit.forward_taps(bb.images, sel); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -49,5 +49,6 @@ for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         torch.cuda.synchronize()
         taps[fold] = t
         print(f"round {rnd} ln_fold={fold} vit: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", flush=True)
-lib.iisan_set_ln_fold(1); lib.iisan_set_full_blocks(0)
-print("production batch, epilogue vs images per tap:", " ".join(f"{rel(taps[1][:, k], taps[0][:, k]):.2e}" for k in range(len(sel))))
+lib.iisan_set_ln_fold(2); lib.iisan_set_full_blocks(0)
+for f in (1, 2):
+    print(f"production batch, ln_fold={f} vs images per tap:", " ".join(f"{rel(taps[f][:, k], taps[0][:, k]):.2e}" for k in range(len(sel))))
