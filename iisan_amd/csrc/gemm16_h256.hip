@@ -353,6 +353,30 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    // EPI_STREAM16: the old stream values of a half-epilogue — 8 x 16 bytes per lane, the same addresses its stores overwrite — are
+    // requested TWO SLOTS before the epilogue that adds them (top of Rlo of the K-step whose [Rhi + E] slot holds that epilogue): the
+    // half-slots in between hold 64 fragment registers less than a full step, which is where the 32 registers come from.  Issued
+    // inside the epilogue they cost O 341 -> 410 us and FC2 1,090 -> 1,156 us: ~3 us of exposed HBM latency per half-epilogue.
+    V8 xo[4][2];
+    auto stream_load = [&](int tm, int tn, int half) {
+        if constexpr (EPI == EPI_STREAM16) {
+            if (p.debug & 128) return;          // ablation: no stream loads (the sums are garbage)
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            const uint32_t lane_off = (uint32_t)((l2 & 31) * p.ldo * 2 + (l2 >> 5) * 32);
+            const char* base = (const char*)p.out + ((int64_t)(tm * SBM + grp * 128 + half * 64) * p.ldo + tn * SBN + wq * 64) * 2;
+            // (inline asm, waited for by hand in the epilogue: the compiler's own `s_waitcnt` for a plain load does not know the LDS-DMA
+            //  pieces issued behind it and came out as `vmcnt(0)` at the top of the epilogue — a wait for the pieces of the MFMA slot
+            //  that has just ended)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const char* bp = base + ((int64_t)((b & 1) * 32) * p.ldo + (b >> 1) * 32) * 2;      // wave-uniform
+                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                             : "=v"(xo[b][0]), "=&v"(xo[b][1]) : "v"(lane_off), "s"(bp) : "memory");
+            }
+            S256_FENCE();
+        }
+    };
     bool stores8 = false;      // the last half-epilogue issued exactly 8 store instructions per wave (full row tile, stores enabled)
     // ---- half-epilogue: rows half*64 .. +63 of the group's 128 (acc[2*half .. 2*half+1][*]) of tile (tm, tn) ----
     // What the slot timelines (tools/gemm_slots_h.py, tools/slots_fine.py) showed.  (1) The s256 epilogue inside a half-slot took
@@ -373,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // stores issued from middle read slots then sit in the CU's in-order vector-memory pipeline in front of the LDS-DMA pieces of
     // the next MFMA slot, which land late: middle slots of 1,500-2,200 cycles appeared and the kernel lost 7 % (QKV 928 against
     // 998 TFLOP/s).  The vector-memory path (128 stores x 92 + 768 DMA pieces per tile) is as busy as the matrix pipe.
-    auto epilogue = [&](int tm, int tn, int half, int sbuf) {
+    auto epilogue = [&](int tm, int tn, int half, int sbuf, bool tail = false) {
         // The lane-dependent offsets are RECOMPUTED here from a laundered lane id: hoisted out of the K loop they stay live
         // across it, the kernel sits at 256 VGPRs, they are spilled, and every scratch reload is followed by an
         // `s_waitcnt vmcnt(0)` — which also waits for the LDS-DMA in flight and the stores.
@@ -404,29 +428,82 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     lane_off = (uint32_t)(frow * p.ldo * 2 + fh * 32);
                 }
                 f4 bbv[4];         // the lane's 16 bias values of column block ni (the same for every 32-row block)
-                // EPI_STREAM16: the lane's 16 old stream values of a block (the same 32 bytes the block's two stores overwrite), requested
-                // one block ahead of their use (all four blocks ahead: 51 registers spilled), and the row sums of the lane's two rows
-                V8 xold[4][2];
-                // (the four blocks' sums wait in a wave-private LDS row — 2 KiB per wave behind the bias — instead of four registers)
-                f2* sSum = (f2*)(sBias + 1024) + (wave * 4) * 64 + lane;
-                auto load_old = [&](int b) {
-                    const int mi = 2 * half + (b & 1), ni = b >> 1;
-                    const char* ip = (const char*)p.out + ((int64_t)(row0 + mi * 32) * p.ldo + col0 + ni * 32) * 2 + lane_off;
-                    xold[b][0] = *(const V8*)ip;
-                    xold[b][1] = *(const V8*)(ip + 16);
-                };
-                constexpr bool PF_STREAM = true;
-                if constexpr (EPI == EPI_STREAM16 && PF_STREAM) { load_old(0); S256_FENCE(); }
+                if constexpr (EPI == EPI_STREAM16) {
+                    // ---- x += acc + bias in the fp16 stream (in place) + the rows' sums over this wave's 64 columns ----
+                    // The old values are in `xo` (stream_load, two slots ago; behind them in the queue: the LDS-DMA pieces of the MFMA slot in
+                    // between — 4 after a last step's Mlo, 8 after a first step's).  A block's packed results go out right behind its arithmetic.
+                    V8 oo[4][2];
+                    if (tail) S256_VMCNT(0); else if (half == 0) S256_VMCNT(4); else S256_VMCNT(8);
+
+                    // the four blocks' sums wait in a wave-private LDS row — 2 KiB per wave behind the bias — instead of four registers
+                    f2* sSum = (f2*)(sBias + 1024) + (wave * 4) * 64 + lane;
+                    auto blk_ptr = [&](int b) {
+                        const int mi = 2 * half + (b & 1), ni = b >> 1;
+                        return (char*)p.out + ((int64_t)(row0 + mi * 32) * p.ldo + col0 + ni * 32) * 2 + lane_off;
+                    };
+                    auto comp = [&](int b) {
+                        const int mi = 2 * half + (b & 1), ni = b >> 1;
+                        // a CLS row (m = item * S, its stream is the executor's fp32 xc) receives the delta alone
+                        const uint32_t m = (uint32_t)(row0 + mi * 32 + frow);
+                        const bool cls = m - __umulhi(m, qkv_magic) * (uint32_t)p.qkv_S == 0u;
+                        f2 s2 = (f2){0.f, 0.f}, q2 = (f2){0.f, 0.f};        // even / odd columns apart: v_pk_add_f32 / v_pk_fma_f32
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            // eight columns at a time, bias re-read from LDS per block (registers, as in the LNA epilogue)
+                            const f4 b0 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf), b1 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf + 4);
+                            // (the launder pins the conversions HERE: left alone they are hoisted above the full / ragged branch, all 16 of
+                            //  a block at once, into a slot that has ~30 free registers: 39-67 spilled)
+                            V8 x8 = xo[b][hf];
+                            asm volatile("" : "+v"(x8));
+                            if (cls) x8 = (V8)(_Float16)0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f2 t = (f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]} + (k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
+                                t += (f2){(float)x8[2 * k], (float)x8[2 * k + 1]};
+                                s2 += t;
+                                q2 = __builtin_elementwise_fma(t, t, q2);
+                                // converted at once: the eight sums of a block never sit in registers together
+                                oo[b][hf][2 * k] = T::from_f32(t[0]); oo[b][hf][2 * k + 1] = T::from_f32(t[1]);
+                            }
+                            S256_FENCE();
+                        }
+                        sSum[b * 64] = (f2){s2[0] + s2[1], q2[0] + q2[1]};
+                        S256_FENCE();
+                    };
+                    auto store = [&](int b) {
+                        const int mi = 2 * half + (b & 1);
+                        char* op = blk_ptr(b);
+                        if (FULL || (int64_t)(row0 + mi * 32 + frow) < p.M) {
+                            *(V8*)op = oo[b][0];
+                            *(V8*)(op + 16) = oo[b][1];
+                        }
+                        S256_FENCE();
+                    };
+                    comp(0); store(0);
+                    comp(1); store(1);
+                    comp(2); store(2);
+                    comp(3); store(3);
+                    // the lane's two rows over this wave's 64 columns: lanes l and l ^ 32 hold the two 16-column halves of both.  One
+                    // v_permlane32_swap per statistic leaves row block 2 half in lanes 0..31 and row block 2 half + 1 in lanes 32..63,
+                    // one 8-byte store per lane: slice-major [N / 64][Mpad] so that a wave writes two 256-byte runs
+                    // (inline asm: this hipcc's __builtin_amdgcn_permlane32_swap returns the first register twice — `v_add_f32 v1, v1, v1`
+                    //  behind the swap — so the builtin's sum is 2 x one half; the swap exchanges a[32..63] with b[0..31] in place)
+                    auto both = [](float a, float b) {
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                        return a + b;
+                    };
+                    const f2 a0 = sSum[0], a1 = sSum[64], a2 = sSum[128], a3 = sSum[192];       // blocks (mi, ni) = (0,0) (1,0) (0,1) (1,1)
+                    const f2 st = (f2){both(a0[0] + a2[0], a1[0] + a3[0]), both(a0[1] + a2[1], a1[1] + a3[1])};
+                    const int64_t slot = (int64_t)(col0 >> 6) * ((int64_t)tiles_m * SBM);
+                    if (!(p.debug & 256)) *(f2*)(p.rowpart + (slot + row0 + (2 * half + fh) * 32 + frow) * 2) = st;      // (ablation bit: no statistics store)
+                    return;
+                }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int mi = 2 * half + (b & 1), ni = b >> 1;
-                    if constexpr (EPI == EPI_STREAM16) {
-                        if (PF_STREAM ? b < 3 : true) load_old(PF_STREAM ? b + 1 : b);
-                        S256_FENCE();
-                    }
                     f2 g[8];       // bias added pairwise: v_pk_add_f32 (8 instead of 16 v_add_f32 per block)
                     V8 o0, o1;
-                    if (!LNA && EPI != EPI_STREAM16 && (b & 1) == 0) {
+                    if (!LNA && (b & 1) == 0) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) bbv[q4] = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 4 * q4);
                     }
@@ -452,34 +529,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                                 g[4 * hf + k] = __builtin_elementwise_fma((f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]}, sx,
                                                                           k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
                         }
-                    } else if constexpr (EPI == EPI_STREAM16) {
-                        // x += acc + bias, eight columns at a time (bias re-read from LDS per block as in the LNA epilogue: registers); a CLS
-                        // row (m = item * S, its stream is the executor's fp32 xc) receives the delta alone
-                        const uint32_t m = (uint32_t)(row0 + mi * 32 + frow);
-                        const bool cls = m - __umulhi(m, qkv_magic) * (uint32_t)p.qkv_S == 0u;
-                        f2 s2 = (f2){0.f, 0.f}, q2 = (f2){0.f, 0.f};        // even / odd columns apart: v_pk_add_f32 / v_pk_fma_f32
-#pragma unroll
-                        for (int hf = 0; hf < 2; ++hf) {
-                            const f4 b0 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf), b1 = *(const f4*)(sBias + col0 + ni * 32 + 16 * fh + 8 * hf + 4);
-                            // (the launder pins the conversions HERE: left alone they are hoisted above the full / ragged branch, all 16 of
-                            //  a block at once, into a slot that has ~30 free registers: 39-67 spilled)
-                            V8 xo = xold[b][hf];
-                            asm volatile("" : "+v"(xo));
-                            if (cls) xo = (V8)(_Float16)0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const f2 x2 = (f2){(float)xo[2 * k], (float)xo[2 * k + 1]};
-                                f2 t = (f2){acc[mi][ni][8 * hf + 2 * k], acc[mi][ni][8 * hf + 2 * k + 1]} + (k < 2 ? (f2){b0[2 * k], b0[2 * k + 1]} : (f2){b1[2 * k - 4], b1[2 * k - 3]});
-                                t += x2;
-                                s2 += t;
-                                q2 = __builtin_elementwise_fma(t, t, q2);
-                                // converted at once: the eight sums of a block never sit in registers together
-                                if (hf == 0) { o0[2 * k] = T::from_f32(t[0]); o0[2 * k + 1] = T::from_f32(t[1]); }
-                                else { o1[2 * k] = T::from_f32(t[0]); o1[2 * k + 1] = T::from_f32(t[1]); }
-                            }
-                            S256_FENCE();
-                        }
-                        sSum[b * 64] = (f2){s2[0] + s2[1], q2[0] + q2[1]};
                     } else {
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
@@ -488,12 +537,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     // (four pairs at a time: the eight-pair form needs 48 temporaries on top of the fragments that stay live
                     //  across this slot, and spilled)
                     if constexpr (EPI == EPI_GELU16) { gelu_erf_fast2xN<4>(g); gelu_erf_fast2xN<4>(g + 4); }
-                    if constexpr (EPI != EPI_STREAM16) {
 #pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
-                            o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
-                        }
+                    for (int e = 0; e < 8; e += 2) {
+                        o0[e] = T::from_f32(g[e / 2][0]); o0[e + 1] = T::from_f32(g[e / 2][1]);
+                        o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
                     }
 #ifdef S256_TIMELINE
                     if (p.debug & 32) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
@@ -527,21 +574,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                             *(V8*)(op + 16) = o1;
                         }
                     }
-                }
-                if constexpr (EPI == EPI_STREAM16) {
-                    // the lane's two rows over this wave's 64 columns: lanes l and l ^ 32 hold the two 16-column halves of both.  One
-                    // v_permlane32_swap per statistic leaves row block 2 half in lanes 0..31 and row block 2 half + 1 in lanes 32..63,
-                    // one 8-byte store per lane: slice-major [N / 64][Mpad] so that a wave writes two 256-byte runs
-                    // (inline asm: this hipcc's __builtin_amdgcn_permlane32_swap returns the first register twice — `v_add_f32 v1, v1, v1`
-                    //  behind the swap — so the builtin's sum is 2 x one half; the swap exchanges a[32..63] with b[0..31] in place)
-                    auto both = [](float a, float b) {
-                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-                        return a + b;
-                    };
-                    const f2 a0 = sSum[0], a1 = sSum[64], a2 = sSum[128], a3 = sSum[192];       // blocks (mi, ni) = (0,0) (1,0) (0,1) (1,1)
-                    const f2 st = (f2){both(a0[0] + a2[0], a1[0] + a3[0]), both(a0[1] + a2[1], a1[1] + a3[1])};
-                    const int64_t slot = (int64_t)(col0 >> 6) * ((int64_t)tiles_m * SBM);
-                    *(f2*)(p.rowpart + (slot + row0 + (2 * half + fh) * 32 + frow) * 2) = st;
                 }
             };
             if (full) run(std::true_type{}); else run(std::false_type{});
@@ -628,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     for (int s = 0; s < nsteps;) {
         {
             // ======== first K-step of a tile: Rlo | Mlo | Rhi + E(hi, previous tile) | Mhi ========
+            if (s > 0) stream_load(prev_tm, prev_tn, 1);
             read_lo(s);
             const Plan q = make_plan(s, 0);
             S256_LGKM0();
@@ -668,10 +701,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         }
         {
             // ======== last K-step of a tile: Rlo | Mlo | Rhi + E(lo) | Mhi ========
+            stream_load(cur_tm, cur_tn, 0);
             read_lo(s);
             const Plan q = make_plan(s, nk - 1);
             S256_LGKM0();
-            S256_VMCNT(0);
+            if constexpr (EPI == EPI_STREAM16) S256_VMCNT(8); else S256_VMCNT(0);      // (the 8 stream loads just issued fly on)
             stamp();
             S256_BARRIER();
             stamp();
@@ -697,7 +731,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
             if (ti + 1 < my_tiles) walk(ti + 1, nxt_tm, nxt_tn);
         }
     }
-    epilogue(prev_tm, prev_tn, 1, (ti - 1) & 1);     // the last tile's hi rows
+    stream_load(prev_tm, prev_tn, 1);
+    epilogue(prev_tm, prev_tn, 1, (ti - 1) & 1, true);     // the last tile's hi rows
     if (grp == 0) S256_BARRIER();      // matches B's last slot
 #ifdef S256_TIMELINE
     if (dbg_on && lane == 0)
