@@ -18,7 +18,7 @@ vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_ui
 
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                                  "ln1_w", "ln1_b", "ln2_w", "ln2_b")]
+                                  "ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w32", "fc1_w32")]
 
 
 class VitWeights(C.Structure):
@@ -92,7 +92,7 @@ EXTRA_SIGNATURES = {
     "iisan_gemm16_h256_applicable": (i32, [i32, i64, i32, i32, i32, i32, i32]),
     "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "iisan_gemm16_lna": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
-    "iisan_fold_ln_weights": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    "iisan_fold_ln_weights": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, vp]),
     "iisan_set_ln_fold": (None, [i32]),
     "iisan_gemm16_stream": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_stream_stats_finalize": (i32, [vp, i32, i64, vp, vp, vp, f32, i64, i32, vp]),

@@ -292,7 +292,9 @@ int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, f
                               float* stat = nullptr);
 // LayerNorm folded into the weights of the product that consumes it (rowops.hip): Wf[n][k] = fp16(gamma[k] W[n][k] - mean_k(gamma W[n]))
 // with sum_k Wf[n][k] = 0 to the last bit that matters, bf[n] = bias[n] + sum_k beta[k] W[n][k]; K = 768, fp16 weights.  Up to 32 jobs in one launch.
-struct LnFoldJob { const void* W; const float* bias; const float* g; const float* b; void* Wf; float* bf; int32_t N; };
+struct LnFoldJob { const void* W; const float* bias; const float* g; const float* b; void* Wf; float* bf; int32_t N;
+                   int32_t w32;    // 1: W is fp32 (the caller's master copy), 0: fp16
+};
 int launch_fold_ln_weights(const LnFoldJob* jobs, int n, hipStream_t s);
 // after an EPI_STREAM16 product: rstat[m] = rstd of row m from the `nslots` partial sums of rowpart [nslots][Mpad][2]; the CLS rows
 // (m = item * Ttok): xc[item] += the fp16 delta the product left in x16[m]; x16[m] = fp16(xc[item]); rstat[m] from the rounded row

@@ -225,8 +225,8 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
         int nj = 0;
         for (int l = 0; l < live; ++l) {
             const iisan_layer_weights& L = w->layer[l];
-            jobs[nj++] = LnFoldJob{L.qkv_w, L.qkv_b, L.ln1_w, L.ln1_b, Wf_qkv(l), bf_qkv(l), 3 * D};
-            if (l + 1 < live || full_blocks) jobs[nj++] = LnFoldJob{L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, Wf_fc1(l), bf_fc1(l), F};
+            jobs[nj++] = LnFoldJob{L.qkv_w32 ? (const void*)L.qkv_w32 : L.qkv_w, L.qkv_b, L.ln1_w, L.ln1_b, Wf_qkv(l), bf_qkv(l), 3 * D, L.qkv_w32 ? 1 : 0};
+            if (l + 1 < live || full_blocks) jobs[nj++] = LnFoldJob{L.fc1_w32 ? (const void*)L.fc1_w32 : L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, Wf_fc1(l), bf_fc1(l), F, L.fc1_w32 ? 1 : 0};
             if (nj >= 31 || l + 1 == live) { IISAN_TRY(launch_fold_ln_weights(jobs, nj, s)); nj = 0; }
         }
     }

@@ -362,9 +362,9 @@ extern "C" int iisan_gemm16_lna(int32_t mode, const void* A, const void* W, cons
 }
 
 // bench / test entry: the weight fold of one LayerNorm + product pair (rowops.hip)
-extern "C" int iisan_fold_ln_weights(const void* W, const float* bias, const float* g, const float* b, void* Wf, float* bf,
+extern "C" int iisan_fold_ln_weights(const void* W, int32_t w32, const float* bias, const float* g, const float* b, void* Wf, float* bf,
                                      int32_t N, void* stream) {
-    LnFoldJob j{W, bias, g, b, Wf, bf, N};
+    LnFoldJob j{W, bias, g, b, Wf, bf, N, w32};
     return launch_fold_ln_weights(&j, 1, (hipStream_t)stream);
 }
 

@@ -551,11 +551,15 @@ extern "C" int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_
 // LN(x) W^T + b = rstd (x Wf^T) + bf with Wf[n][k] = gamma[k] W[n][k] - (1/K) sum_j gamma[j] W[n][j] — CENTRED rows: sum_k x[k] Wf[n][k] =
 // sum_k (x[k] - mean(x)) gamma[k] W[n][k] for every x, so the product of the un-normalised row needs no mean correction — and
 // bf = b + W beta.  The fp16 rounding of Wf leaves a row sum d_n = sum_k (Wf16 - Wf) != 0 and with it an error mean(x) rstd d_n that
-// grows with |mean| / std of the row (CPU emulation: 1.7e-4 -> 5.1e-4 relative at |mean| = 3 std with round-to-nearest).  So the
-// rounding DIFFUSES its error along the row (each lane carries the error of an element into the next of its 24, the 32 lanes' last
-// carries are added to one element): |d_n| <= half an ulp of one weight, ~1e-5 of the ~4e-4 round-to-nearest leaves, at the price of
-// errors up to one ulp instead of half in the single weights.  The weights are frozen, but the ABI is stateless: folded once per
-// forward call (200 MB of traffic for ViT-B, ~40 us) into the workspace.
+// grows with |mean| / std of the row (CPU emulation: 1.7e-4 -> 5.1e-4 relative at |mean| = 3 std with round-to-nearest, |d_n| ~ 8 ulp).
+// SUM-PRESERVING ROUNDING: round to nearest, then move the few elements whose rounding was the closest call (residual nearest +-1/2
+// ulp, on the side d_n needs) to their other neighbour — a bisection over the residual threshold finds the set whose ulps add up to
+// d_n; each such move costs next to nothing ((1 - 2|r|) ulp^2 of squared error at residual r ~ 1/2), so the weights keep the noise of
+// plain rounding (the first version diffused every element's error into its neighbour: row sums as good, 1.4 x the noise) — and what
+// the bisection leaves (< one ulp) goes into one element.  |d_n| ends below one ulp of one weight, ~1e-5 of the ~4e-4 plain rounding
+// leaves.  W is read from the caller's fp32 master when the weights struct has one (iisan_layer_weights.qkv_w32 / fc1_w32): ONE rounding
+// of gamma W - mean instead of a second one on top of the 16-bit copy's.  The weights are frozen, but the ABI is stateless: folded once
+// per forward call (200-300 MB of traffic for ViT-B, ~40-60 us) into the workspace.
 // Half a wave per weight row (K = 768: three 8-element pieces per lane), 8 rows per workgroup, every job in one launch.
 struct LnFoldArgs { LnFoldJob j[32]; int32_t row0[33]; int32_t n; };
 
@@ -567,42 +571,98 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(LnFoldArgs a) {
     while (row >= a.row0[ji + 1]) ++ji;
     const LnFoldJob& J = a.j[ji];
     const int n = row - a.row0[ji];
-    const _Float16* w = (const _Float16*)J.W + (int64_t)n * 768;
     _Float16* wf = (_Float16*)J.Wf + (int64_t)n * 768;
+    auto sum32 = [](float t) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
     float v[3][8];
     float cs = 0.f, bw = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = i * 256 + lane * 8;
-        const h8 x = *(const h8*)(w + c);
+        float x[8];
+        if (J.w32) {
+            const float* w = (const float*)J.W + (int64_t)n * 768 + c;
+            const f4 x0 = *(const f4*)w, x1 = *(const f4*)(w + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = x0[e]; x[4 + e] = x1[e]; }
+        } else {
+            const h8 xh = *(const h8*)((const _Float16*)J.W + (int64_t)n * 768 + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)xh[e];
+        }
         const f4 g0 = *(const f4*)(J.g + c), g1 = *(const f4*)(J.g + c + 4), b0 = *(const f4*)(J.b + c), b1 = *(const f4*)(J.b + c + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float xe = (float)x[e];
-            v[i][e] = xe * (e < 4 ? g0[e] : g1[e - 4]);
+            v[i][e] = x[e] * (e < 4 ? g0[e] : g1[e - 4]);
             cs += v[i][e];
-            bw += xe * (e < 4 ? b0[e] : b1[e - 4]);
+            bw += x[e] * (e < 4 ? b0[e] : b1[e - 4]);
         }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { cs += __shfl_xor(cs, o, 64); bw += __shfl_xor(bw, o, 64); }
+    cs = sum32(cs); bw = sum32(bw);
     const float mu = cs * (1.0f / 768.0f);
-    h8 o16[3];
-    float carry = 0.f;                      // rounding error not yet given back: target - emitted, over the lane's elements so far
+    // round to nearest; r = residual in units of the element's OWN ulp towards the side the row sum needs (dir = sign of the total residual)
+    _Float16 o[3][8];
+    float res = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float t = (v[i][e] - mu) + carry;
-            o16[i][e] = (_Float16)t;
-            carry = t - (float)o16[i][e];
+            v[i][e] -= mu;
+            o[i][e] = (_Float16)v[i][e];
+            res += v[i][e] - (float)o[i][e];
         }
-    float rest = carry;
+    const float R = sum32(res);                       // what the emitted row is short of (target - emitted)
+    const float dir = R >= 0.f ? 1.f : -1.f;
+    // the neighbour of o on the `dir` side and what moving there adds to the row sum (its ulp on that side)
+    float step[3][8], frac[3][8];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
-    if (lane == 0) o16[0][0] = (_Float16)((float)o16[0][0] + rest);       // the lanes' last carries: into one element
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) *(h8*)(wf + i * 256 + lane * 8) = o16[i];
+        for (int e = 0; e < 8; ++e) {
+            const float of = (float)o[i][e];
+            const unsigned short bits = __builtin_bit_cast(unsigned short, o[i][e]);
+            // next representable half away from / towards zero: +-1 on the magnitude bits (zero: the smallest subnormal of sign dir)
+            const bool up_mag = (of > 0.f) == (dir > 0.f) || of == 0.f;
+            unsigned short nb = of == 0.f ? (unsigned short)(dir > 0.f ? 1 : 0x8001) : (unsigned short)(up_mag ? bits + 1 : bits - 1);
+            const float nf = (float)__builtin_bit_cast(_Float16, nb);
+            step[i][e] = (nf - of) * dir;                                    // > 0
+            frac[i][e] = (v[i][e] - of) * dir / step[i][e];                  // in [-1/2, 1/2]: how far the target lies towards that neighbour
+        }
+    // bisection over the threshold t: move every element with frac > t; moved(t) decreases from ~sum of all steps (t = -1/2) to 0 (t = 1/2)
+    float lo = 0.f, hi = 0.5f;                        // elements with frac <= 0 were rounded away from that side: never moved
+    const float need = R * dir;                       // >= 0
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
+        const float t = 0.5f * (lo + hi);
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m += frac[i][e] > t ? step[i][e] : 0.f;
+        m = sum32(m);
+        if (m > need) lo = t; else hi = t;            // too much moved: raise the threshold
+    }
+    float moved = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (frac[i][e] > hi) {
+                o[i][e] = (_Float16)((float)o[i][e] + dir * step[i][e]);
+                moved += step[i][e];
+            }
+    const float rest = (need - sum32(moved)) * dir;   // |rest| < one ulp of the last element not moved: into one element, re-rounded
+    if (lane == 0) o[0][0] = (_Float16)((float)o[0][0] + rest);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        h8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = o[i][e];
+        *(h8*)(wf + i * 256 + lane * 8) = o8;
+    }
     if (lane == 0) J.bf[n] = (J.bias ? J.bias[n] : 0.f) + bw;
 }
 

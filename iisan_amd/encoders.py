@@ -66,9 +66,13 @@ class _PackedEncoder:
         self._keep.append(t)
         return _ptr(t)
 
-    def _layers(self, struct, n_layers: int):
+    def _layers(self, struct, n_layers: int, masters: bool = False):
+        """masters: also keep the fp32 originals of qkv_w / fc1_w on the device (`iisan_layer_weights.qkv_w32 / fc1_w32`): the ViT
+        executor folds its LayerNorms into these two matrices and then rounds to fp16 once, not twice."""
         for l in range(n_layers):
             p, L = f"L{l}.", struct.layer[l]
+            if masters:
+                L.qkv_w32, L.fc1_w32 = self._v32(p + "qkv_w"), self._v32(p + "fc1_w")
             L.qkv_w, L.qkv_b = self._m16(p + "qkv_w"), self._v32(p + "qkv_b")
             L.o_w, L.o_b = self._m16(p + "o_w"), self._v32(p + "o_b")
             L.fc1_w, L.fc1_b = self._m16(p + "fc1_w"), self._v32(p + "fc1_b")
@@ -88,7 +92,7 @@ class PackedVit(_PackedEncoder):
         s.image, s.patch, s.channels, s.dtype16, s.eps = cfg.image, cfg.patch, cfg.channels, dtype16, cfg.eps
         s.patch_w, s.patch_b = self._m16("patch_w"), self._v32("patch_b")
         s.cls_token, s.pos_emb = self._v32("cls_token"), self._v32("pos_emb")
-        self._layers(s, cfg.layers)
+        self._layers(s, cfg.layers, masters=dtype16 == _lib.IISAN_F16)
         self.struct = s
         self._w = None
 

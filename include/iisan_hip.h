@@ -55,6 +55,10 @@ typedef struct {
     const void* fc2_w;  const float* fc2_b;   /* [D,F], [D]                                                     */
     const float* ln1_w; const float* ln1_b;   /* ViT: layernorm_before;  BERT: attention.output.LayerNorm       */
     const float* ln2_w; const float* ln2_b;   /* ViT: layernorm_after;   BERT: output.LayerNorm                 */
+    /* OPTIONAL fp32 masters of qkv_w / fc1_w (null = none).  The ViT executor with fp16 operands folds LayerNorm 1 / 2 into
+     * these two matrices at the start of every call (gamma-scaled, centred rows); given the masters it rounds the
+     * folded rows to fp16 ONCE instead of re-rounding the 16-bit copies (tap error against the reference 1.09e-3 -> see DESIGN). */
+    const float* qkv_w32; const float* fc1_w32;
 } iisan_layer_weights;
 
 typedef struct {

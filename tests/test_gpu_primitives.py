@@ -145,39 +145,38 @@ def _ln_fold_case(M, N, K, row_mean, seed):
     return x16, gamma, beta, W, b, rstd.reshape(-1).contiguous(), ln32
 
 
+@pytest.mark.parametrize("w32", [1, 0])
 @pytest.mark.parametrize("row_mean", [0.3, 3.0])
-def test_layernorm_fold_of_the_weights_is_centred_and_sum_preserving(lib, row_mean):
-    """Round 5: `fold_ln_weights_kernel` (rowops.hip) — Wf[n] = fp16(gamma * W[n] - mean_k(gamma * W[n])), bias' = b + W beta.  Every
-    folded element within one ulp of the row's largest weight of its target (rms 1.4 x plain rounding), the ROW SUMS within one ulp of zero (plain rounding leaves ~20x that: the sum is what
-    multiplies the mean of an activation row), and LN(x) W^T + b == rstd * (x Wf^T) + bias' to fp16-operand accuracy in fp64
-    arithmetic — also for rows whose mean is several standard deviations."""
+def test_layernorm_fold_of_the_weights_is_centred_and_sum_preserving(lib, row_mean, w32):
+    """Round 5: `fold_ln_weights_kernel` (rowops.hip) — Wf[n] = fp16(gamma * W[n] - mean_k(gamma * W[n])), bias' = b + W beta, from the
+    caller's fp32 master (w32) or from the fp16 copy.  Sum-preserving rounding: every folded element within ONE ulp of its target with
+    the rms of plain rounding (a handful per row are moved to their other neighbour), the ROW SUMS within one ulp of one weight of
+    zero (plain rounding leaves ~20x that: the sum is what multiplies the mean of an activation row), and LN(x) W^T + b ==
+    rstd * (x Wf^T) + bias' to fp16-operand accuracy in fp64 arithmetic — also for rows whose mean is several standard deviations."""
     N, K = 2304, 768
     x16, gamma, beta, W, b, rstd, ln32 = _ln_fold_case(512, N, K, row_mean, 11)
-    Wf = torch.empty_like(W); bf = torch.empty(N, device="cuda")
-    _lib.check(lib.iisan_fold_ln_weights(W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
+    W32 = W.float() * (1.0 + 2.0 ** -13) if w32 else None                 # a master that is NOT fp16-representable
+    Wsrc = W32 if w32 else W
+    Wf = torch.empty(N, K, dtype=torch.float16, device="cuda"); bf = torch.empty(N, device="cuda")
+    _lib.check(lib.iisan_fold_ln_weights(Wsrc.data_ptr(), w32, b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
     torch.cuda.synchronize()
-    Wg = W.double() * gamma.double()
+    Wg = Wsrc.double() * gamma.double()
     Wc = Wg - Wg.mean(1, keepdim=True)
     ulp = 2.0 ** -10 * Wc.abs().clamp_min(2.0 ** -14)                     # fp16 spacing at the element's magnitude (upper bound)
     err = (Wf.double() - Wc).abs()
-    # an element's error = the carry it received - the carry it passes on: half an ulp of its predecessor in the lane's chain + half
-    # an ulp of its own — at most one ulp of the row's largest weight, and on average 1.4 x plain rounding
-    rowmax_ulp = 2.0 ** -10 * Wc.abs().max(1, keepdim=True).values
-    assert (err[:, 1:] <= rowmax_ulp).all()
-    assert err[:, 1:].pow(2).mean().sqrt().item() < 1.6 * (Wc.half().double() - Wc)[:, 1:].pow(2).mean().sqrt().item()
-    # column 0 takes the 32 lanes' last carries: a few ulps of the row's LARGEST weights, whatever its own size
-    assert (err[:, 0] <= 17 * 2.0 ** -11 * Wc.abs().max(1).values).all()
+    assert (err[:, 1:] <= 1.001 * ulp[:, 1:]).all()
+    # column 0 takes what the bisection leaves: under one ulp of the row's LARGEST weights, whatever its own size
+    assert (err[:, 0] <= 1.5 * 2.0 ** -10 * Wc.abs().max(1).values).all()
+    plain = Wc.half().double()
+    assert err[:, 1:].pow(2).mean().sqrt().item() < 1.1 * (plain - Wc)[:, 1:].pow(2).mean().sqrt().item()
     sums = Wf.double().sum(1).abs()
-    plain = Wc.half().double().sum(1).abs()
     assert sums.max().item() <= 2.0 ** -10 * Wc.abs().max().item(), sums.max().item()
-    assert sums.max().item() < 0.2 * plain.max().item(), (sums.max().item(), plain.max().item())
-    assert (bf.double() - (b.double() + W.double() @ beta.double())).abs().max().item() < 1e-5
-    ref = ln32.double() @ W.double().t() + b.double()
+    assert sums.max().item() < 0.2 * plain.sum(1).abs().max().item(), (sums.max().item(), plain.sum(1).abs().max().item())
+    assert (bf.double() - (b.double() + Wsrc.double() @ beta.double())).abs().max().item() < 1e-5
+    ref = ((x16.double() - x16.double().mean(1, keepdim=True)) * rstd.double()[:, None] * gamma.double() + beta.double()) @ Wsrc.double().t() + b.double()
     alg = rstd.double()[:, None] * (x16.double() @ Wf.double().t()) + bf.double()
-    img = ln32.half().double() @ W.double().t() + b.double()
     e_alg = ((alg - ref).norm() / ref.norm()).item()
-    e_img = ((img - ref).norm() / ref.norm()).item()
-    assert e_alg < 2.0 * e_img and e_alg < 4e-4, (e_alg, e_img)          # measured 2.6e-4 against 1.6e-4: the second rounding of the weights, diffused
+    assert e_alg < 2.2e-4, e_alg            # one rounding of the weights (measured ~1.6e-4: what rounding LayerNorm(x) to fp16 costs the other route)
 
 
 @pytest.mark.parametrize("case", [("qkv", 4, 2304, 197 * 335), ("fc1", 1, 3072, 277376), ("fc1", 1, 3072, 1500)])
@@ -191,7 +190,7 @@ def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
     K, S = 768, 197
     x16, gamma, beta, W, b, rstd, ln32 = _ln_fold_case(M, N, K, 0.3, N + M)
     Wf = torch.empty_like(W); bf = torch.empty(N, device="cuda")
-    _lib.check(lib.iisan_fold_ln_weights(W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
+    _lib.check(lib.iisan_fold_ln_weights(W.data_ptr(), 0, b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, _stream()), "fold")
     Mp = x16.shape[0]
     outs = []
     try:

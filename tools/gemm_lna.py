@@ -30,7 +30,7 @@ for name, N, mode in (("qkv", 2304, 4), ("fc1", 3072, 1)):
     W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
     b = torch.randn(N, device="cuda", generator=g)
     Wf = torch.empty_like(W); bf = torch.empty(N, device="cuda")
-    assert lib.iisan_fold_ln_weights(W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, st) == 0
+    assert lib.iisan_fold_ln_weights(W.data_ptr(), 0, b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wf.data_ptr(), bf.data_ptr(), N, st) == 0
     torch.cuda.synchronize()
     Wg = W.float() * gamma
     Wc = Wg - Wg.mean(1, keepdim=True)
