@@ -339,7 +339,8 @@ def pmc_traffic(a):
     with open(path) as f:
         d = json.load(f)
     # the committed passes must be of THIS default (round 3 flipped it to every block on every token)
-    return float(d["avg_bytes_per_launch"]) if d.get("encoder_blocks") == "all tokens in every block" else None
+    # ... and of THIS kernel set (round 4, second half: the O / FC2 products read and write the residual stream in their epilogues — iisan_set_ln_fold 2)
+    return float(d["avg_bytes_per_launch"]) if d.get("encoder_blocks") == "all tokens in every block" and d.get("ln_fold") == 2 else None
 
 
 class Uncached:
@@ -390,7 +391,7 @@ class Uncached:
         need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
         self.model.eval()
         self.set_full_blocks(self.a.full_blocks)
-        # round 5: at this size the ViT tower applies its LayerNorms and residual adds in the GEMM epilogues (iisan_set_ln_fold, default 2),
+        # round 4, second half: at this size the ViT tower applies its LayerNorms and residual adds in the GEMM epilogues (iisan_set_ln_fold, default 2),
         # a different ROUNDING SEQUENCE from the 128x128 kernels' LayerNorm images.  Three legs: "img" = the production kernels on the
         # image route (kernel families alone differ: 4e-4), "auto" = the product default (what the timed steps run: inside the 1.5e-3 tap
         # budget against the pinned kernels, loss within the north-star 1e-3), "v1" = the pinned 128x128 kernels.

@@ -108,7 +108,7 @@ def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
     vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda")
     bert = encoders.PackedBert(bw, weights.BERT_BASE, "cuda")
     sel = [0, 2, 4, 6, 8, 10, 12]
-    # round 5: at this size the ViT tower applies its LayerNorms in the epilogues of the QKV / FC1 products (gamma-folded, centred
+    # round 4, second half: at this size the ViT tower applies its LayerNorms in the epilogues of the QKV / FC1 products (gamma-folded, centred
     # weights; `iisan_set_ln_fold`), which the 128x128 kernels do not do — a different rounding sequence, not a different kernel
     # family.  So two production runs: LayerNorm images (the kernels alone differ: tight bound) and the default (bound = the
     # decorrelated 16-bit operand noise, as between the fp32 and the mixed stream above).

@@ -148,7 +148,7 @@ def _ln_fold_case(M, N, K, row_mean, seed):
 @pytest.mark.parametrize("w32", [1, 0])
 @pytest.mark.parametrize("row_mean", [0.3, 3.0])
 def test_layernorm_fold_of_the_weights_is_centred_and_sum_preserving(lib, row_mean, w32):
-    """Round 5: `fold_ln_weights_kernel` (rowops.hip) — Wf[n] = fp16(gamma * W[n] - mean_k(gamma * W[n])), bias' = b + W beta, from the
+    """Round 4 (second half): `fold_ln_weights_kernel` (rowops.hip) — Wf[n] = fp16(gamma * W[n] - mean_k(gamma * W[n])), bias' = b + W beta, from the
     caller's fp32 master (w32) or from the fp16 copy.  Sum-preserving rounding: every folded element within ONE ulp of its target with
     the rms of plain rounding (a handful per row are moved to their other neighbour), the ROW SUMS within one ulp of one weight of
     zero (plain rounding leaves ~20x that: the sum is what multiplies the mean of an activation row), and LN(x) W^T + b ==
@@ -181,7 +181,7 @@ def test_layernorm_fold_of_the_weights_is_centred_and_sum_preserving(lib, row_me
 
 @pytest.mark.parametrize("case", [("qkv", 4, 2304, 197 * 335), ("fc1", 1, 3072, 277376), ("fc1", 1, 3072, 1500)])
 def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
-    """Round 5: `gemm16_h256_kernel<.., LNA = true>` — LayerNorm applied by the epilogue of the product that consumes it: A = the
+    """Round 4 (second half): `gemm16_h256_kernel<.., LNA = true>` — LayerNorm applied by the epilogue of the product that consumes it: A = the
     un-normalised fp16 rows, W = the folded weights, one rstd per row (brought in per tile by LDS-DMA), out = rstd * acc + bias'.
     EVERY element is held to fp32 arithmetic (GELU) / to the same kernel on the materialised LayerNorm image (head-major QKV) over
     three launches that must agree bit for bit: the first version of this epilogue let the compiler broadcast the statistic by
@@ -221,7 +221,7 @@ def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
 
 @pytest.mark.parametrize("case", [(768, 1408), (3072, 352), (768, 9)])
 def test_gemm16_h256_stream_epilogue_adds_into_the_stream_and_leaves_row_sums(lib, case):
-    """Round 5: `EPI_STREAM16` — the residual add of a pre-LN tower in the epilogue of the O / FC2 products: x[m] = fp16(x[m] + A[m] W^T
+    """Round 4 (second half): `EPI_STREAM16` — the residual add of a pre-LN tower in the epilogue of the O / FC2 products: x[m] = fp16(x[m] + A[m] W^T
     + b) in place in the fp16 stream, (sum, sum of squares) of every new row over each 64-column slice, the CLS rows (m = item * S)
     receive the delta alone; `stream_stats_finalize` turns the sums into rstd in a fixed order and folds the CLS deltas into their
     fp32 stream.  Every element against fp32 arithmetic, the partial sums against torch, three launches bit-identical."""

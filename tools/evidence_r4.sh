@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence in one gpurun call: kernel traces, HBM-side traffic (PMC, two passes each) and matrix-pipe counters of the four
+# The round's evidence in one gpurun call: kernel traces, HBM-side traffic (PMC, two passes each) and matrix-pipe counters of the four
 # bench configurations.  usage: bash tools/evidence_r4.sh <tag> [parts: trace pmc mfma]      -> gpurun_out/ev_<tag>/
 tag=${1:-r4}; parts=${2:-"trace pmc mfma"}
 cd /tmp && export TMPDIR=/tmp
@@ -30,6 +30,8 @@ if [[ $parts == *pmc* ]]; then
   f=$(pass head FETCH_SIZE $HEAD2); w=$(pass head WRITE_SIZE $HEAD2)
   python3 tools/pmc_traffic.py $f $w gemm16 > $out/pmc_head_gemm16.md 2>&1
   python3 tools/pmc_traffic.py $f $w layernorm768 > $out/pmc_head_ln.md 2>&1
+  python3 tools/pmc_traffic.py $f $w stream_stats > $out/pmc_head_finalize.md 2>&1
+  python3 tools/pmc_traffic.py $f $w fold_ln > $out/pmc_head_fold.md 2>&1
   python3 tools/pmc_traffic.py $f $w attention16 > $out/pmc_head_attn.md 2>&1
   f=$(pass cached FETCH_SIZE $C3 --steps 2 --warmup 1); w=$(pass cached WRITE_SIZE $C3 --steps 2 --warmup 1)
   python3 tools/pmc_traffic.py --step $f $w 5 cached_fp32_bs1024 $out/pmc_traffic_cached.json > $out/pmc_cached.md 2>&1

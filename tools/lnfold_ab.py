@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the ViT tower with its LayerNorms applied in the epilogues of the QKV / FC1 products (iisan_set_ln_fold(1), round 5: the add
+"""A/B of the ViT tower with its LayerNorms applied in the epilogues of the QKV / FC1 products (iisan_set_ln_fold(1), round 4: the add
 kernels write the fp16 stream + rstd per row, the products read the stream against gamma-folded, centred weights) against the
 LayerNorm images of round 4.  Per-layer tap error against the reference's golden taps (4 items; gemm16_h256 forced, which is what
 the production batch runs) and forward time of the production batch (1,408 item slots, every block on every token)."""
