@@ -12,7 +12,7 @@ void iisan_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" const char* iisan_version(void) { return "iisan_hip 0.4 (round 4)"; }
+extern "C" const char* iisan_version(void) { return "iisan_hip 0.5 (round 4b)"; }
 extern "C" const char* iisan_arch(void) { return "gfx950"; }
 extern "C" const char* iisan_last_error(void) { return g_err; }
 

@@ -91,6 +91,9 @@ typedef struct {
  * images fp32 [M,C,R,R] -> taps fp32 [M, n_taps, D], taps[:,k] = CLS row of hidden state tap_layers[k]
  * (0 = embeddings, l = output of layer l; the last one is before the final LayerNorm).  `tap_layers` is a host
  * array.  `chunk_items` (0 = whole batch) bounds the activation working set. */
+/* fp16 operands (dtype16 = IISAN_F16), production sizes: the executor folds LayerNorm 1 / 2 of every block into the QKV / FC1
+ * weights at the start of the call (workspace: +99 MB for ViT-B) and runs no LayerNorm / residual-add kernel inside blocks 1..L-1
+ * (DESIGN 6g); the taps stay inside the same tolerance against the reference (tests/test_gpu_encoders.py). */
 size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items);
 int iisan_vit_forward_taps(const iisan_vit_weights* w, const float* images, int64_t M,
                            const int32_t* tap_layers, int32_t n_taps, float* taps,

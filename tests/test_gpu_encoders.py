@@ -96,6 +96,51 @@ def test_fp32_residual_stream_and_mixed_stream_both_match_the_golden(lib):
             assert _rel(out[(0, fb)][0][:, l], out[(1, fb)][0][:, l]) < 1e-3 and _rel(out[(0, fb)][1][:, l], out[(1, fb)][1][:, l]) < 1e-3
 
 
+def test_layernorm_and_adds_in_the_gemm_epilogues_match_the_golden(lib):
+    """Round 4 (second half): with fp16 operands the ViT executor applies LayerNorm 1 / 2 in the epilogues of the QKV / FC1 products
+    (gamma-folded, centred weights from the fp32 masters, one rstd per row) and the residual adds in the epilogues of the O / FC2 products
+    (`iisan_set_ln_fold`: 0 = LayerNorm images, 1 = LayerNorm in the epilogues + add kernels, 2 = the default).  Those epilogues exist in
+    `gemm16_h256_kernel` only, which the 4-item golden fixture reaches with the kernel forced (variant 4): every route, with every block on
+    every token and with the CLS-only last block, must sit inside the same budget against the reference's golden taps, tap by tap; the
+    routes must really differ (or the knob did nothing) and agree with each other within the 16-bit operand noise."""
+    z, vw, bw, b = gio.encoders_full_inputs()
+    vit = encoders.PackedVit(vw, weights.VIT_BASE, "cuda")
+    ref_c = torch.from_numpy(z["taps_cv"])
+    layers = list(range(13))
+    out = {}
+    try:
+        lib.iisan_set_gemm16_variant(4)
+        for fold in (0, 1, 2):
+            lib.iisan_set_ln_fold(fold)
+            for fb in (0, 1):
+                lib.iisan_set_full_blocks(fb)
+                out[(fold, fb)] = vit.forward_taps(b.images.cuda(), layers).cpu()
+        # without the fp32 masters the fold re-rounds the 16-bit copies: still inside the budget
+        for l in range(vit.cfg.layers):
+            vit.struct.layer[l].qkv_w32 = None
+            vit.struct.layer[l].fc1_w32 = None
+        lib.iisan_set_ln_fold(2)
+        lib.iisan_set_full_blocks(1)
+        out["no masters"] = vit.forward_taps(b.images.cuda(), layers).cpu()
+    finally:
+        lib.iisan_set_gemm16_variant(0)
+        lib.iisan_set_ln_fold(2)
+        lib.iisan_set_full_blocks(0)
+    tol = TAP_TOL[_lib.IISAN_F16]
+    for key, tc in out.items():
+        assert torch.isfinite(tc).all()
+        assert torch.equal(tc[:, 0], out[(0, 1)][:, 0])
+        for l in range(1, 13):
+            assert _rel(tc[:, l], ref_c[:, l]) < tol, (key, l, _rel(tc[:, l], ref_c[:, l]))
+    for fb in (0, 1):
+        assert not torch.equal(out[(1, fb)], out[(0, fb)]) and not torch.equal(out[(2, fb)], out[(1, fb)])
+        for l in range(1, 13):
+            assert _rel(out[(2, fb)][:, l], out[(0, fb)][:, l]) < 1.3e-3 and _rel(out[(1, fb)][:, l], out[(0, fb)][:, l]) < 1.3e-3
+    # measured: tap 12 at 9.0e-4 (images), 9.5e-4 (1), 9.3e-4 (2), 1.09e-3 without the masters
+    assert _rel(out[(2, 1)][:, 12], ref_c[:, 12]) < 1.05e-3
+    assert not torch.equal(out["no masters"], out[(2, 1)])
+
+
 def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
     """BASELINE config 2 shape: 1,408 item slots (bs=128) through the DEFAULT dispatch — the persistent 256x256 kernels
     on QKV/O/FC1/FC2 (277,376 ViT token rows, 42,240 BERT rows), the production attention grid — must give, within 16-bit
