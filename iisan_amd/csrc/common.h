@@ -282,7 +282,9 @@ int launch_add2_layernorm768(int dtype16, const float* x, const void* delta16, c
                              const float* b, float eps, float* sum32, void* out16, float* out32, int64_t rows, hipStream_t s);
 // mixed-precision residual stream (rowops.hip: layernorm768_mixed_kernel): CLS rows fp32 in `xc` [items, 768], every other token
 // row fp16 in `x16` [items * Ttok, 768]; V = which operands exist
-enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64, MX_POSROW = 128, MX_STAT = 256 };
+enum { MX_D1 = 1, MX_D2 = 2, MX_LN = 4, MX_RESV = 8, MX_RESY = 16, MX_SRC32 = 32, MX_CLSONLY = 64, MX_POSROW = 128, MX_STAT = 256, MX_ALIAS = 512 };
+// MX_ALIAS (with MX_RESY, fp16 operands): out16 IS x16 — the post-LN tower's stream and its LayerNorm image are the same fp16 values, written
+// once (every row, the CLS rows too; their fp32 copy still goes to xc)
 // MX_STAT (with MX_RESV, without MX_LN): no LayerNorm image; every row's sum goes to the fp16 stream (the CLS rows as well: the stream
 // is the next GEMM's A operand) and `stat` [rows] receives rstd of the ROUNDED row — Gemm16Args::rowstat
 // MX_POSROW (with MX_SRC32 | MX_D1): the fp32 source is a [Ttok, 768] table indexed by the TOKEN (the position embedding) and the delta is

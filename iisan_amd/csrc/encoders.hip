@@ -377,13 +377,17 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
         const int64_t tok = mc * T;
         float* tp = taps + m0 * n_taps * D;
         const bool mixed = !g_resid32;
-        // post-LN tower: the stream IS the LayerNorm output.  resid32: X fp32 [tok, D]; mixed: Xc fp32 (CLS rows) + X16 fp16
+        // post-LN tower: the stream IS the LayerNorm output.  resid32: X fp32 [tok, D]; mixed: Xc fp32 (CLS rows) + X16 fp16.  With fp16
+        // operands the 16-bit image the products read and the fp16 stream are the same values: one buffer, written once (g_ln_fold; the add +
+        // LayerNorm kernels move 6 instead of 8 bytes per element)
+        const bool alias = mixed && dt == IISAN_F16 && g_ln_fold;
+        void* IMG = alias ? b.X16 : b.H;
         IISAN_TRY(launch_bert_embed_ln(dt, text + m0 * 2 * words, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_w,
-                                       w->emb_ln_b, w->eps, mixed ? nullptr : b.X, b.H, b.KB, mc, T, w->vocab, s, b.X16, b.Xc));
+                                       w->emb_ln_b, w->eps, mixed ? nullptr : b.X, IMG, b.KB, mc, T, w->vocab, s, b.X16, b.Xc));
         auto tap = [&](int k) { return mixed ? launch_gather_cls(b.Xc, tp, mc, 1, D, n_taps, k, s) : launch_gather_cls(b.X, tp, mc, T, D, n_taps, k, s); };
         // x = LN(x + delta): stream and 16-bit image out
         auto add_ln = [&](const float* g, const float* be) {
-            return mixed ? launch_layernorm768_mixed(dt, MX_D1 | MX_LN | MX_RESY, nullptr, b.X16, b.Xc, b.D16, nullptr, g, be, w->eps, b.H, mc, T, s)
+            return mixed ? launch_layernorm768_mixed(dt, MX_D1 | MX_LN | MX_RESY | (alias ? MX_ALIAS : 0), nullptr, b.X16, b.Xc, b.D16, nullptr, g, be, w->eps, IMG, mc, T, s)
                          : launch_add_layernorm768(dt, b.X, b.D16, g, be, w->eps, nullptr, b.H, b.X, tok, s);
         };
         int k = tap_index(tap_layers, n_taps, 0);
@@ -394,12 +398,12 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
             const iisan_layer_weights& L = w->layer[l];
             // a = LN(x + O(attn(x)))
             if (l + 1 < live || full_blocks) {
-                IISAN_TRY(gemm(dt, EPI_QKVH16, b.H, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
+                IISAN_TRY(gemm(dt, EPI_QKVH16, IMG, D, L.qkv_w, L.qkv_b, b.QKV, 3 * D, nullptr, tok, s, nullptr, 0, T, w->heads));
                 IISAN_TRY(launch_attention16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, tok, s));
                 IISAN_TRY(add_ln(L.ln1_w, L.ln1_b));
                 // x = LN(a + FC2(gelu(FC1 a)))
-                IISAN_TRY(gemm(dt, EPI_GELU16, b.H, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
+                IISAN_TRY(gemm(dt, EPI_GELU16, IMG, D, L.fc1_w, L.fc1_b, b.F1, F, nullptr, tok, s));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.F1, F, L.fc2_w, L.fc2_b, b.D16, D, nullptr, tok, s));
                 IISAN_TRY(add_ln(L.ln2_w, L.ln2_b));
                 k = tap_index(tap_layers, n_taps, l + 1);
@@ -408,8 +412,8 @@ extern "C" int iisan_bert_forward_taps(const iisan_bert_weights* w, const int64_
                 // post-LN tower: the block input H is the 16-bit image of X, so the CLS rows of H are gathered directly
                 void* Hc = b.Cls;
                 void* Qc = (char*)b.Cls + (size_t)b.Mcp * D * 2;
-                IISAN_TRY(launch_gather_rows16(b.H, Hc, mc, T, D, s));
-                IISAN_TRY(kv_all_q_cls(dt, L, b.H, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
+                IISAN_TRY(launch_gather_rows16(IMG, Hc, mc, T, D, s));
+                IISAN_TRY(kv_all_q_cls(dt, L, IMG, b.QKV, Hc, Qc, tok, mc, T, w->heads, D, s));
                 float* Xc = (float*)b.QKV;
                 IISAN_TRY(launch_attention_cls16(dt, b.QKV, b.KB, b.H, mc, T, w->heads, s, Qc));
                 IISAN_TRY(gemm(dt, EPI_OUT16, b.H, D, L.o_w, L.o_b, b.D16, D, nullptr, mc, s));

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
                                                                  float* __restrict__ stat) {
     constexpr bool D1 = (V & MX_D1) != 0, D2 = (V & MX_D2) != 0, LN = (V & MX_LN) != 0, RESV = (V & MX_RESV) != 0,
                    RESY = (V & MX_RESY) != 0, SRC32 = (V & MX_SRC32) != 0, CLSONLY = (V & MX_CLSONLY) != 0, POSROW = (V & MX_POSROW) != 0,
-                   STAT = (V & MX_STAT) != 0;
+                   STAT = (V & MX_STAT) != 0, ALIAS = (V & MX_ALIAS) != 0;
     typedef typename T::v8 V8;
     const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;          // 8 half-waves per workgroup
     int64_t item;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void layernorm768_mixed_kernel(const float* __
             *(f4*)(xc + item * 768 + i * 256 + lane * 8) = (f4){val[0], val[1], val[2], val[3]};
             *(f4*)(xc + item * 768 + i * 256 + lane * 8 + 4) = (f4){val[4], val[5], val[6], val[7]};
         }
-        if (!cls || STAT) {
+        if ((!cls || STAT) && !ALIAS) {
             h8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (_Float16)val[e];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __res
             *(f4*)(X + row * 768 + c) = y;
         } else if (t == 0) {                 // mixed-precision residual stream: CLS rows fp32 (compact), the others fp16
             *(f4*)(Xc + m * 768 + c) = y;
-        } else {
+        } else if ((const void*)H != (const void*)X16) {     // (H == X16: the fp16 image is the stream — one store below covers every row)
             typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
             hv4 xh;
 #pragma unroll
@@ -413,6 +413,7 @@ int launch_layernorm768_mixed(int dtype16, int V, const float* x32, void* x16, f
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_LN);          // ViT LN1: x += dO + dF; LN
         MX_CASE(MX_D1 | MX_D2 | MX_RESV | MX_CLSONLY);     // ViT closing add of the CLS rows (hidden state 12)
         MX_CASE(MX_D1 | MX_LN | MX_RESY);                  // BERT: x = LN(x + d)
+        MX_CASE(MX_D1 | MX_LN | MX_RESY | MX_ALIAS);       // BERT, fp16 operands: ... and the image IS the stream
         // LayerNorm applied by the consuming product (Gemm16Args::rowstat): the stream and the row statistics only
         MX_CASE(MX_SRC32 | MX_POSROW | MX_D1 | MX_RESV | MX_STAT);   // ViT block 0
         MX_CASE(MX_D1 | MX_RESV | MX_STAT);                // ViT LN1 (x += dF) and LN2 (x += dO)
