@@ -219,18 +219,19 @@ def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
         assert not outs[0][M:].any()    # rows beyond M are not written
 
 
-@pytest.mark.parametrize("case", [(768, 1408), (3072, 352), (768, 9)])
+@pytest.mark.parametrize("case", [(768, 1408), (3072, 352), (768, 9), (128, 1408), (192, 40)])
 def test_gemm16_h256_stream_epilogue_adds_into_the_stream_and_leaves_row_sums(lib, case):
     """Round 4 (second half): `EPI_STREAM16` — the residual add of a pre-LN tower in the epilogue of the O / FC2 products: x[m] = fp16(x[m] + A[m] W^T
     + b) in place in the fp16 stream, (sum, sum of squares) of every new row over each 64-column slice, the CLS rows (m = item * S)
     receive the delta alone; `stream_stats_finalize` turns the sums into rstd in a fixed order and folds the CLS deltas into their
-    fp32 stream.  Every element against fp32 arithmetic, the partial sums against torch, three launches bit-identical."""
+    fp32 stream.  Every element against fp32 arithmetic, the partial sums against torch, three launches bit-identical; K = 128 / 192:
+    tiles of two / three K-steps (no middle step between the two prefetches of old stream values), fewer tiles than CUs."""
     K, items = case
     S, N = 197, 768
     M = items * S
     g = torch.Generator(device="cuda").manual_seed(K + items)
     A = _pad_rows((torch.randn(M, K, generator=g, device="cuda") * 0.5).half())
-    W = (torch.randn(N, K, generator=g, device="cuda") * (0.05 if K == 768 else 0.025)).half()
+    W = (torch.randn(N, K, generator=g, device="cuda") * (0.025 if K == 3072 else 0.05)).half()
     b = torch.randn(N, generator=g, device="cuda") * 0.3
     x0 = _pad_rows((torch.randn(M, N, generator=g, device="cuda") * 1.5 + 0.2).half())
     x0[:, 7] += 20.0
