@@ -36,6 +36,14 @@
 //   B Mhi(0') [9]: W 128..255 of 2'-> read in [11],[12];                                       waited at the end of [10]
 // (the whole W fragment set of a step is read in Rlo, the A-operand rows 0..63 in Rlo and 64..127 in Rhi).
 // Tile walk, LDS swizzle, operand swap / W-row permutation, fences and the 16-bit epilogues are those of gemm16_s256.hip.
+//
+// Round 4, second half — two epilogue families that remove every kernel between the products of a pre-LN block:
+//   LNA (template flag; EPI_QKVH16 / EPI_GELU16, fp16): A is the un-normalised residual stream, W the gamma-folded, centred weights
+//        (rowops.hip: fold_ln_weights_kernel); the epilogue multiplies by one rstd per row — the tile's 256 values arrive by one LDS-DMA
+//        instruction at the top of the tile's first [Rhi + E] slot, two buffers — where the plain epilogue adds the bias.
+//   EPI_STREAM16 (fp16, N <= 1024): the O / FC2 products add into the fp16 stream in place (x = fp16(x + acc + b)) and leave per-slice
+//        row sums for stream_stats_finalize (rowops.hip).  The old stream values of a half-epilogue are requested two slots ahead
+//        (stream_load: inline-asm loads, waits by hand — `vmcnt` is in order and the LDS-DMA pieces queue behind them).
 #include "common.h"
 #include <type_traits>
 
