@@ -25,7 +25,7 @@ class VitWeights(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("mlp", i32),
                 ("image", i32), ("patch", i32), ("channels", i32), ("dtype16", i32), ("eps", f32), ("full_blocks", i32),
                 ("patch_w", vp), ("patch_b", vp), ("cls_token", vp), ("pos_emb", vp),
-                ("layer", LayerWeights * MAX_LAYERS)]
+                ("layer", LayerWeights * MAX_LAYERS), ("folded", vp)]
 
 
 class BertWeights(C.Structure):
@@ -53,6 +53,8 @@ SIGNATURES = {
     "iisan_arch": (C.c_char_p, []),
     "iisan_last_error": (C.c_char_p, []),
     "iisan_vit_forward_taps_ws_bytes": (sz, [C.POINTER(VitWeights), i64, i64]),
+    "iisan_vit_fold_bytes": (sz, [C.POINTER(VitWeights)]),
+    "iisan_vit_fold_layernorm": (i32, [C.POINTER(VitWeights), vp, sz, vp]),
     "iisan_vit_forward_taps": (i32, [C.POINTER(VitWeights), vp, i64, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_vit_forward_taps_u8": (i32, [C.POINTER(VitWeights), vp, i64, C.POINTER(i32), i32, vp, i64, vp, sz, vp]),
     "iisan_bert_forward_taps_ws_bytes": (sz, [C.POINTER(BertWeights), i64, i32, i64]),

@@ -46,7 +46,7 @@ int g_resid32 = 0;
 // 0: the LayerNorm image of rounds 1-4.  Bench / test knob.
 int g_ln_fold = 2;
 
-size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems, int fold_layers = 0) {
+size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int F, int64_t kb_elems, int fold_layers = 0, bool fold_ws = true) {
     const int64_t Tp = ceil_div(tokens, 256) * 256;     // GEMM A operands are read in 256-row tiles
     b.Mcp = ceil_div(items, 256) * 256;
     b.Cls = c.take<uint16_t>((size_t)2 * b.Mcp * D);
@@ -62,8 +62,10 @@ size_t carve(WsCarver& c, EncBufs& b, int64_t tokens, int64_t items, int D, int 
     b.KB = c.take<float>((size_t)(kb_elems > 0 ? kb_elems : 1));
     b.Wf = nullptr; b.Bf = nullptr; b.RS = nullptr; b.RP = nullptr;
     if (fold_layers > 0) {
-        b.Wf = c.take<uint16_t>((size_t)fold_layers * (3 * D + F) * D);
-        b.Bf = c.take<float>((size_t)fold_layers * (3 * D + F));
+        if (fold_ws) {          // (not when the caller's weights struct carries the folded set)
+            b.Wf = c.take<uint16_t>((size_t)fold_layers * (3 * D + F) * D);
+            b.Bf = c.take<float>((size_t)fold_layers * (3 * D + F));
+        }
         b.RS = c.take<float>((size_t)Tp);
         b.RP = c.take<float>((size_t)(D / 64) * Tp * 2);
     }
@@ -141,6 +143,39 @@ extern "C" void iisan_set_ln_fold(int32_t on) { g_ln_fold = on; }
 static int vit_fold_layers(const iisan_vit_weights* w) {
     return (!g_resid32 && g_ln_fold && w->dtype16 == IISAN_F16) ? w->layers : 0;
 }
+// the folded set of one tower: [layers][(3D + F) x D] fp16, then [layers][3D + F] fp32 (the caller's `folded` buffer or the workspace)
+static size_t vit_fold_w_elems(const iisan_vit_weights* w) { return (size_t)(3 * w->hidden + w->mlp) * w->hidden; }
+static int vit_fold_all(const iisan_vit_weights* w, int layers, bool last_fc1, char* Wf, float* Bf, hipStream_t s) {
+    const int D = w->hidden, F = w->mlp;
+    LnFoldJob jobs[32];
+    int nj = 0;
+    for (int l = 0; l < layers; ++l) {
+        const iisan_layer_weights& L = w->layer[l];
+        char* wq = Wf + (size_t)l * vit_fold_w_elems(w) * 2;
+        float* bq = Bf + (size_t)l * (3 * D + F);
+        jobs[nj++] = LnFoldJob{L.qkv_w32 ? (const void*)L.qkv_w32 : L.qkv_w, L.qkv_b, L.ln1_w, L.ln1_b, wq, bq, 3 * D, L.qkv_w32 ? 1 : 0};
+        if (l + 1 < layers || last_fc1)
+            jobs[nj++] = LnFoldJob{L.fc1_w32 ? (const void*)L.fc1_w32 : L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, wq + (size_t)3 * D * D * 2, bq + 3 * D, F, L.fc1_w32 ? 1 : 0};
+        if (nj >= 31 || l + 1 == layers) { IISAN_TRY(launch_fold_ln_weights(jobs, nj, s)); nj = 0; }
+    }
+    return IISAN_OK;
+}
+
+extern "C" size_t iisan_vit_fold_bytes(const iisan_vit_weights* w) {
+    if (w->dtype16 != IISAN_F16 || w->hidden != 768) return 0;
+    return (size_t)w->layers * (vit_fold_w_elems(w) * 2 + (size_t)(3 * w->hidden + w->mlp) * 4);
+}
+
+extern "C" int iisan_vit_fold_layernorm(const iisan_vit_weights* w, void* folded, size_t bytes, void* stream) {
+    const size_t need = iisan_vit_fold_bytes(w);
+    IISAN_CHECK_SHAPE(need > 0, "vit_fold_layernorm: fp16 operands and hidden size 768 only");
+    if (!folded || bytes < need) {
+        iisan_set_error("vit_fold_layernorm: buffer too small (%zu < %zu)", bytes, need);
+        return IISAN_EWORKSPACE;
+    }
+    IISAN_CHECK_SHAPE(w->layers >= 1 && w->layers <= IISAN_MAX_LAYERS, "vit_fold_layernorm: layers %d out of range", w->layers);
+    return vit_fold_all(w, w->layers, true, (char*)folded, (float*)((char*)folded + (size_t)w->layers * vit_fold_w_elems(w) * 2), (hipStream_t)stream);
+}
 
 extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, int64_t M, int64_t chunk_items) {
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
@@ -148,7 +183,7 @@ extern "C" size_t iisan_vit_forward_taps_ws_bytes(const iisan_vit_weights* w, in
     const int pd = w->channels * w->patch * w->patch;
     WsCarver c(nullptr, 0);
     EncBufs b;
-    return carve(c, b, Mc * (P + 1), Mc, w->hidden, w->mlp > pd ? w->mlp : pd, 0, vit_fold_layers(w));
+    return carve(c, b, Mc * (P + 1), Mc, w->hidden, w->mlp > pd ? w->mlp : pd, 0, vit_fold_layers(w), w->folded == nullptr);
 }
 
 static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images, int img_u8, int64_t M,
@@ -182,7 +217,11 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
     const int64_t Mc = (chunk_items > 0 && chunk_items < M) ? chunk_items : M;
     WsCarver c(ws, ws_bytes);
     EncBufs b;
-    carve(c, b, Mc * T, Mc, D, F > pd ? F : pd, 0, vit_fold_layers(w));
+    carve(c, b, Mc * T, Mc, D, F > pd ? F : pd, 0, vit_fold_layers(w), w->folded == nullptr);
+    if (w->folded && b.RS) {       // the caller folded once (iisan_vit_fold_layernorm)
+        b.Wf = const_cast<void*>(w->folded);
+        b.Bf = (float*)((char*)b.Wf + (size_t)w->layers * vit_fold_w_elems(w) * 2);
+    }
     if (c.overflow || !ws) {
         iisan_set_error("vit_forward_taps: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
@@ -220,16 +259,7 @@ static int vit_forward_taps_impl(const iisan_vit_weights* w, const void* images,
     auto Wf_fc1 = [&](int l) { return Wf_qkv(l) + (size_t)3 * D * D * 2; };
     auto bf_qkv = [&](int l) { return b.Bf + (size_t)l * (3 * D + F); };
     auto bf_fc1 = [&](int l) { return bf_qkv(l) + 3 * D; };
-    if (lna) {
-        LnFoldJob jobs[32];
-        int nj = 0;
-        for (int l = 0; l < live; ++l) {
-            const iisan_layer_weights& L = w->layer[l];
-            jobs[nj++] = LnFoldJob{L.qkv_w32 ? (const void*)L.qkv_w32 : L.qkv_w, L.qkv_b, L.ln1_w, L.ln1_b, Wf_qkv(l), bf_qkv(l), 3 * D, L.qkv_w32 ? 1 : 0};
-            if (l + 1 < live || full_blocks) jobs[nj++] = LnFoldJob{L.fc1_w32 ? (const void*)L.fc1_w32 : L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, Wf_fc1(l), bf_fc1(l), F, L.fc1_w32 ? 1 : 0};
-            if (nj >= 31 || l + 1 == live) { IISAN_TRY(launch_fold_ln_weights(jobs, nj, s)); nj = 0; }
-        }
-    }
+    if (lna && !w->folded) IISAN_TRY(vit_fold_all(w, live, full_blocks, (char*)b.Wf, b.Bf, s));
     const int64_t img_elems = (int64_t)w->channels * w->image * w->image;
     for (int64_t m0 = 0; m0 < M; m0 += Mc) {
         const int64_t mc = (M - m0 < Mc) ? M - m0 : Mc;

@@ -95,6 +95,14 @@ class PackedVit(_PackedEncoder):
         self._layers(s, cfg.layers, masters=dtype16 == _lib.IISAN_F16)
         self.struct = s
         self._w = None
+        # LayerNorm 1 / 2 folded into the QKV / FC1 weights once, here, instead of at the start of every forward call
+        lib = _lib.load()
+        nbytes = lib.iisan_vit_fold_bytes(C.byref(s))
+        if nbytes and self.device.type == "cuda":
+            self._folded = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.iisan_vit_fold_layernorm(C.byref(s), _ptr(self._folded), nbytes, _stream()), "iisan_vit_fold_layernorm")
+            s.folded = _ptr(self._folded)
 
     def forward_taps(self, images: torch.Tensor, tap_layers: Sequence[int], chunk_items: int = 0) -> torch.Tensor:
         """images fp32 [M,C,R,R] (normalised) or uint8 [M,C,R,R] (raw pixels, normalised on the device) -> fp32

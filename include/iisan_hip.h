@@ -72,6 +72,10 @@ typedef struct {
     const float* cls_token;                   /* [D]                                                            */
     const float* pos_emb;                     /* [T, D], T = (image/patch)^2 + 1                                */
     iisan_layer_weights layer[IISAN_MAX_LAYERS];
+    /* OPTIONAL (null = none): the LayerNorm-folded QKV / FC1 weights of every layer, filled ONCE by iisan_vit_fold_layernorm into a
+     * caller-owned device buffer of iisan_vit_fold_bytes() bytes.  Without it every forward call folds them again into its workspace
+     * (300 MB of traffic, ~0.1 ms for ViT-B; the result is the same). */
+    const void* folded;
 } iisan_vit_weights;
 
 typedef struct {
@@ -91,6 +95,11 @@ typedef struct {
  * images fp32 [M,C,R,R] -> taps fp32 [M, n_taps, D], taps[:,k] = CLS row of hidden state tap_layers[k]
  * (0 = embeddings, l = output of layer l; the last one is before the final LayerNorm).  `tap_layers` is a host
  * array.  `chunk_items` (0 = whole batch) bounds the activation working set. */
+/* The folded weights of `w` (LayerNorm 1 / 2 of every layer folded into qkv_w / fc1_w: gamma-scaled, centred, fp16, rounded
+ * sum-preservingly from the fp32 masters when the layer has them, + the folded biases): [layers][(3D + F) x D] fp16, then
+ * [layers][3D + F] fp32.  0 bytes when the executor would not use them (bf16 operands). */
+size_t iisan_vit_fold_bytes(const iisan_vit_weights* w);
+int iisan_vit_fold_layernorm(const iisan_vit_weights* w, void* folded, size_t bytes, void* stream);
 /* fp16 operands (dtype16 = IISAN_F16), production sizes: the executor folds LayerNorm 1 / 2 of every block into the QKV / FC1
  * weights at the start of the call (workspace: +99 MB for ViT-B) and runs no LayerNorm / residual-add kernel inside blocks 1..L-1
  * (DESIGN 6g); the taps stay inside the same tolerance against the reference (tests/test_gpu_encoders.py). */

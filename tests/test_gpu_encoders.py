@@ -115,12 +115,17 @@ def test_layernorm_and_adds_in_the_gemm_epilogues_match_the_golden(lib):
             for fb in (0, 1):
                 lib.iisan_set_full_blocks(fb)
                 out[(fold, fb)] = vit.forward_taps(b.images.cuda(), layers).cpu()
+        # the weights struct carries the set folded once at pack time (iisan_vit_fold_layernorm); without it every call folds into its
+        # workspace — the same bits
+        lib.iisan_set_ln_fold(2)
+        lib.iisan_set_full_blocks(1)
+        assert vit.struct.folded
+        vit.struct.folded = None
+        out["folded per call"] = vit.forward_taps(b.images.cuda(), layers).cpu()
         # without the fp32 masters the fold re-rounds the 16-bit copies: still inside the budget
         for l in range(vit.cfg.layers):
             vit.struct.layer[l].qkv_w32 = None
             vit.struct.layer[l].fc1_w32 = None
-        lib.iisan_set_ln_fold(2)
-        lib.iisan_set_full_blocks(1)
         out["no masters"] = vit.forward_taps(b.images.cuda(), layers).cpu()
     finally:
         lib.iisan_set_gemm16_variant(0)
@@ -139,6 +144,7 @@ def test_layernorm_and_adds_in_the_gemm_epilogues_match_the_golden(lib):
     # measured: tap 12 at 9.0e-4 (images), 9.5e-4 (1), 9.3e-4 (2), 1.09e-3 without the masters
     assert _rel(out[(2, 1)][:, 12], ref_c[:, 12]) < 1.05e-3
     assert not torch.equal(out["no masters"], out[(2, 1)])
+    assert torch.equal(out["folded per call"], out[(2, 1)])
 
 
 def test_production_batch_dispatch_matches_the_golden_pinned_kernels(lib):
