@@ -16,7 +16,7 @@ std::vector<hipEvent_t> g_pool;
 hipEvent_t take() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
@@ -31,19 +31,19 @@ bool iisan_timing_on(hipStream_t s) { return g_on == 1 && (!g_filter || s == g_o
 int iisan_timing_class() { return g_on; }
 void iisan_timing_pre(hipStream_t s, double flops, double bytes) {
     Rec r{take(), take(), flops, bytes};
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
 }
-void iisan_timing_post(hipStream_t s) { hipEventRecord(g_recs.back().b, s); }
+void iisan_timing_post(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
 
 extern "C" void iisan_timing_enable(int cls) { g_on = cls; }
 // Synchronises on the recorded events; returns the number of launches and fills total milliseconds / total FLOPs.
 extern "C" int64_t iisan_timing_collect(double* total_ms, double* total_flops) {
     double ms = 0, fl = 0, by = 0;
     for (auto& r : g_recs) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float t = 0;
-        hipEventElapsedTime(&t, r.a, r.b);
+        (void)hipEventElapsedTime(&t, r.a, r.b);
         ms += t;
         fl += r.flops;
         by += r.bytes;
