@@ -617,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 #else
     auto stamp = [] {};
     auto stamp2 = [] {};
+    (void)stamp2;
 #endif
     if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
