@@ -339,7 +339,7 @@ def pmc_traffic(a):
     with open(path) as f:
         d = json.load(f)
     # the committed passes must be of THIS default (round 3 flipped it to every block on every token)
-    # ... and of THIS kernel set (round 4, second half: the O / FC2 products read and write the residual stream in their epilogues — iisan_set_ln_fold 2)
+    # ... and of THIS kernel set (round 4, second half: the O / FC2 products read and write the residual stream in their epilogues — dev switch `ln_fold` 2)
     return float(d["avg_bytes_per_launch"]) if d.get("encoder_blocks") == "all tokens in every block" and d.get("ln_fold") == 2 else None
 
 
@@ -391,20 +391,20 @@ class Uncached:
         need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
         self.model.eval()
         self.set_full_blocks(self.a.full_blocks)
-        # round 4, second half: at this size the ViT tower applies its LayerNorms and residual adds in the GEMM epilogues (iisan_set_ln_fold, default 2),
+        # round 4, second half: at this size the ViT tower applies its LayerNorms and residual adds in the GEMM epilogues (dev switch `ln_fold`, default 2),
         # a different ROUNDING SEQUENCE from the 128x128 kernels' LayerNorm images.  Three legs: "img" = the production kernels on the
         # image route (kernel families alone differ: 4e-4), "auto" = the product default (what the timed steps run: inside the 1.5e-3 tap
         # budget against the pinned kernels, loss within the north-star 1e-3), "v1" = the pinned 128x128 kernels.
         try:
             with torch.no_grad():
                 for leg, v, fold in (("auto", 0, 2), ("img", 0, 0), ("v1", 1, 2)):
-                    self.lib.iisan_set_gemm16_variant(v)
-                    self.lib.iisan_set_ln_fold(fold)
+                    _lib.dev_set("gemm16_variant", v)
+                    _lib.dev_set("ln_fold", fold)
                     loss[leg] = float(self.model(self.ids, b.images, b.text, b.log_mask, None).item())
                     taps[leg] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
         finally:
-            self.lib.iisan_set_gemm16_variant(0)
-            self.lib.iisan_set_ln_fold(2)
+            _lib.dev_set("gemm16_variant", 0)
+            _lib.dev_set("ln_fold", 2)
             self.set_full_blocks(False)
             self.model.train()
 
@@ -478,6 +478,7 @@ class Uncached:
         slots = a.bs * 11
         value = slots * world * steps / elapsed
         gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        traffic = pmc_traffic(a) if (headline and dtype == a.dtype and full_blocks == a.full_blocks) else None
         return {
             "metric": "items/s (fwd+bwd) ViT-B+BERT-B IISAN uncached, Scientific, bs=128",
             "value": value, "unit": "items/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -487,26 +488,33 @@ class Uncached:
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        **({"distributed": dinfo} if dinfo else {}),
-                       "towers": ("text tower on a second HIP stream beside the image tower (same kernels, same results); `roofline` times the "
+                       "towers": ("text tower on a second HIP stream beside the image tower (same kernels, same results); `roofline.dominant_kernel` times the "
                                   "gemm16 launches of the main stream = the ViT tower (87 % of the encoder GEMM FLOPs)") if overlapped
-                                 else "both towers on one stream; `roofline` times every gemm16 launch",
+                                 else "both towers on one stream; `roofline.dominant_kernel` times every gemm16 launch",
                        "encoder_blocks": "all tokens in every block" if full_blocks else
                                          "WORK PRUNING: last block computes K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
-            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / (MFMA_PEAK / 1e12),
-                         # bytes per launch at the L2's memory side (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes of
-                         # this command with this configuration, profiles/pmc_traffic.json; null for any other configuration)
-                         "traffic": pmc_traffic(a) if (headline and dtype == a.dtype and full_blocks == a.full_blocks) else None,
-                         "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1),
-                         "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders"
-                                   + (", ViT tower = the launches on the main stream" if overlapped else "") + "; flops = executed, by launch)",
-                         "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
-                         "flop_per_launch": fl.value / max(n_launch, 1),
-                         # whole step: GEMM FLOPs actually executed in the timed region / wall time / peak (dead work the
-                         # executors skip is NOT counted); and the same with the reference's algorithmic 40.28 GFLOP per
-                         # slot, which counts the skipped last-block work as if done — quoted for comparison only
-                         "whole_step_frac": fl.value / elapsed / MFMA_PEAK,
-                         "whole_step_frac_reference_flops": value / world * FLOP_PER_SLOT / MFMA_PEAK},
+            # SURVEY 8d's definition: the WHOLE forward+backward step against the dense 16-bit MFMA peak —
+            # items/s per GPU x 40.28 GFLOP of algorithmic work per item slot (ViT 35.126 + BERT 5.129 forward + the side network
+            # forward and backward) / 2.5 PFLOP/s.  north_star's target is frac >= 0.40 (24,827 items/s).  With work pruning
+            # (`encoder_blocks` says so) the skipped last-block work counts as done: such a line is never the headline.
+            "roofline": {"bound": "mfma", "achieved": value / world * FLOP_PER_SLOT / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": value / world * FLOP_PER_SLOT / MFMA_PEAK,
+                         "definition": "whole step (SURVEY 8d): items/s per GPU x 40.28e9 FLOP per item slot / 2.5e15",
+                         "executed_gemm_flops_frac": fl.value / elapsed / MFMA_PEAK,
+                         # bytes per launch of the dominant kernel at the L2's memory side: NOT measured by this run (PMC counters
+                         # cannot be read from inside it) but read from the committed summary of two rocprofv3 --pmc passes of this
+                         # command with this configuration; null for any other configuration
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected per MI355X_MICROARCH.md; per gemm16 launch)" if traffic is not None else None,
+                         # the dominant kernel class, measured live with HIP events on the launching stream around every launch
+                         "dominant_kernel": {
+                             "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders"
+                                       + (", ViT tower = the launches on the main stream" if overlapped else "") + "; flops = executed, by launch)",
+                             "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                             "frac": gemm_tflops / (MFMA_PEAK / 1e12),
+                             "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
+                             "flop_per_launch": fl.value / max(n_launch, 1),
+                             "ms_per_step": ms.value / max(steps, 1),
+                             "traffic": traffic, "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1)}},
         }
 
 
@@ -660,7 +668,7 @@ def main():
     from iisan_amd import _lib
     lib = _lib.load()
     if a.x3 != 1:                       # 1 = the library's own default: leave the knob untouched
-        lib.iisan_set_x3(a.x3)
+        _lib.dev_set("x3", a.x3)
     if a.eval:
         out = eval_line(a, lib, dev, rank, world)
     elif a.cached:

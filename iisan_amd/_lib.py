@@ -82,41 +82,21 @@ SIGNATURES = {
     "iisan_gemm_x3": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp, sz, vp]),
     "iisan_gather_taps": (i32, [i32, vp, i64, vp, vp, i64, i64, vp]),
     "iisan_cast16": (i32, [i32, vp, vp, i64, vp]),
-}
-
-# bench-only helpers (not declared in include/iisan_hip.h)
-EXTRA_SIGNATURES = {
-    "iisan_set_full_blocks": (None, [i32]),          # process-wide OVERRIDE of the weights structs' `full_blocks` field (tests, bench)
-    "iisan_timing_enable": (None, [i32]),
-    "iisan_timing_only_stream": (None, [vp, i32]),
-    "iisan_set_gemm16_variant": (None, [i32]),
-    "iisan_set_gemm16_walk": (None, [i32, i32]),
-    "iisan_gemm16_h256_applicable": (i32, [i32, i64, i32, i32, i32, i32, i32]),
+    # kernel-level entry points of the encoder GEMM's epilogue families (tests, tools)
     "iisan_gemm16_ld": (i32, [i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_gemm16_lna": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_fold_ln_weights": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, vp]),
-    "iisan_set_ln_fold": (None, [i32]),
     "iisan_gemm16_stream": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "iisan_stream_stats_finalize": (i32, [vp, i32, i64, vp, vp, vp, f32, i64, i32, vp]),
-    "iisan_set_gemm16_desync": (None, [i32]),
-    "iisan_set_gemm16_h256": (None, [i32]),
-    "iisan_set_attn_debug": (None, [i32]),
-    "iisan_set_resid32": (None, [i32]),
-    "iisan_set_x3": (None, [i32]),
-    "iisan_set_sanb_fused": (None, [i32]),
-    "iisan_set_sanb_debug": (None, [i32]),
-    "iisan_set_sanb_schedule": (None, [i32, i32]),
-    "iisan_set_sasrec_fused": (None, [i32]),
-    "iisan_set_sasrec_stamps": (None, [vp]),
-    "iisan_set_ce_debug": (None, [i32]),
-    "iisan_set_ce_fast": (None, [i32]),
-    "iisan_gemm16_f32": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
-    "iisan_set_gemm32_accum_scratch": (None, [i32]),
-    "iisan_set_gemm32_tuning": (None, [i32, i32]),
-    "iisan_set_gemm32_k64": (None, [i32]),
-    "iisan_set_gemm32_dw": (None, [i32]),
-    "iisan_set_gemm32_k64_gate": (None, [i32]),
-    "iisan_set_gemm32_n64f": (None, [i32]),
+    "iisan_gemm16_h256_applicable": (i32, [i32, i64, i32, i32, i32, i32, i32]),
+    # DEV section: the library's only process-global state (development switches + measurement hooks)
+    "iisan_dev_set": (i32, [C.c_char_p, i64]),
+    "iisan_dev_get": (i64, [C.c_char_p]),
+    "iisan_dev_state": (sz, [C.c_char_p, sz, i32]),
+    "iisan_dev_reset": (None, []),
+    "iisan_timing_enable": (None, [i32]),
+    "iisan_timing_only_stream": (None, [vp, i32]),
     "iisan_timing_collect": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "iisan_timing_last_bytes": (C.c_double, []),
 }
@@ -142,27 +122,73 @@ def load():
     # top of it reports "no ROCm-capable device" (seen with build() followed by smoke() in one interpreter).
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA_SIGNATURES.items()):
+    for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent: loud by design
         fn.restype = res
         fn.argtypes = args
-    # development aid (profiling a non-default route under rocprofv3): IISAN_DEV_KNOBS="sanb_fused=0,gemm32_k64=1" calls the
-    # one-argument iisan_set_<name>(int) knobs once at load time.  Unset in every product, test and bench run — and never
-    # silent: one stderr line says which kernels were re-routed, and bench.py copies `dev_knobs()` into its `config`.
+    _lib = lib
+    # development aid (profiling a non-default route under rocprofv3): IISAN_DEV_KNOBS="sanb_fused=0,gemm32_k64=1" sets the named
+    # development switches (include/iisan_hip.h, DEV section) once at load time.  Unset in every product, test and bench run — and
+    # never silent: one stderr line says which kernels were re-routed, and bench.py copies `dev_knobs()` into its `config`.
     for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")):
         name, val = kv.split("=")
-        getattr(lib, "iisan_set_" + name.strip())(int(val))
+        dev_set(name.strip(), int(val))
     if dev_knobs():
         import sys
-        print(f"iisan_amd: IISAN_DEV_KNOBS={dev_knobs()!r} is set: product kernel routes are overridden for this process",
+        print(f"iisan_amd: development switches {dev_knobs()!r} are set: product kernel routes are overridden for this process",
               file=sys.stderr, flush=True)
-    _lib = lib
     return lib
 
 
 def dev_knobs() -> str:
-    """The IISAN_DEV_KNOBS override string of this process ('' = none: the product routes)."""
-    return ",".join(kv.strip() for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")))
+    """Every development switch of this process that is NOT at its library default ('' = none: the product routes)."""
+    return dev_state()
+
+
+def dev_set(name: str, value: int) -> None:
+    """Set one named development switch of the library (tests / bench A/Bs only; raises on an unknown name)."""
+    lib = load()
+    if lib.iisan_dev_set(name.encode(), int(value)) != 0:
+        raise IisanHipError(lib.iisan_last_error().decode())
+
+
+def dev_get(name: str) -> int:
+    lib = load()
+    v = lib.iisan_dev_get(name.encode())
+    if v == -(1 << 63):
+        raise IisanHipError(lib.iisan_last_error().decode())
+    return v
+
+
+def dev_state(all_knobs: bool = False) -> str:
+    """'name=value,...' of every development switch that is NOT at its library default ('' = the product routes)."""
+    lib = load()
+    n = lib.iisan_dev_state(None, 0, int(all_knobs))
+    buf = C.create_string_buffer(n + 1)
+    lib.iisan_dev_state(buf, n + 1, int(all_knobs))
+    return buf.value.decode()
+
+
+def dev_reset() -> None:
+    load().iisan_dev_reset()
+
+
+class dev:
+    """Context manager: `with _lib.dev(ln_fold=0, gemm16_variant=4): ...` sets the switches and restores their previous values."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.old = {k: dev_get(k) for k in self.knobs}
+        for k, v in self.knobs.items():
+            dev_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            dev_set(k, v)
+        return False
 
 
 def check(rc: int, what: str):

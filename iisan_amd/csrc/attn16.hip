@@ -22,7 +22,7 @@
 #endif
 
 static int g_attn_dbg = 0;
-extern "C" void iisan_set_attn_debug(int v) { g_attn_dbg = v; }
+IISAN_DEV_KNOB(attn_debug, g_attn_dbg);
 
 namespace {
 
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
     constexpr int SP = NT16 * 16;
     // V^T row stride (elements), see VT_LD below; (history: 264 = 132 dwords was chosen for a half-wave (16 d-rows x 2 key
     // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
-    constexpr int VT_LD = SP > 128 ? 212 : SP + 8;     // 106 dwords = 10 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (round 3: 260 = 130 dwords, same property; 264 gave 2-way conflicts, PMC).  212 >= 208 + 4 keeps K + V^T + the key limits at 54,592 bytes: three workgroups per CU
+    constexpr int VT_LD = SP > 208 ? 260 : (SP > 128 ? 212 : SP + 8);     // 106 dwords = 10 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (round 3: 260 = 130 dwords, same property; 264 gave 2-way conflicts, PMC).  212 >= 208 + 4 keeps K + V^T + the key limits at 54,592 bytes: three workgroups per CU; 14 tiles (S = 209..224) need a stride >= 224 + 4: 260 (with 212 the V^T rows of neighbouring head dims overlapped and the last one ran into the key limits)
+    static_assert(VT_LD >= SP + 4, "a V^T row holds SP keys and the 16-key tail read reaches SP - 16 + 12 + 4");
     constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
     constexpr int KP = (SP + 31) / 32;                // K passes: 32 rows per pass (the last may be partial: NT16 odd)
     constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass
@@ -435,14 +436,10 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
         if (want > 0 && heads % want == 0) hpw = want;
     }
     dim3 grid((unsigned)(items * (heads / hpw))), block(256);
-    // g_attn_dbg bit 5 (32): the three-workgroups-per-CU kernel without register prefetch (A/B knob, tools/attn_pf_ab.py: same-process
-    // rounds on the ViT shape 415-421 us against 398-411 us for the prefetching kernel with two workgroups per CU — the default; both
-    // carry round 4's 16-key tail product: bit-identical outputs, -3..6 % against round 3's 424 us)
-#define IISAN_ATTN_CASE(NT)                                                                                        \
-    if (!(g_attn_dbg & 32))                                                                                        \
-        hipLaunchKernelGGL((attention16_kernel<T, NT, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31); \
-    else                                                                                                           \
-        hipLaunchKernelGGL((attention16_kernel<T, NT, false>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
+    // (round 4 measured a three-workgroups-per-CU instantiation without register prefetch, PF = false: 415-421 us against 398-411 us per
+    //  ViT layer for this one; it is no longer instantiated — round 5 route retirement)
+#define IISAN_ATTN_CASE(NT) \
+    hipLaunchKernelGGL((attention16_kernel<T, NT, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
     if (S <= 32) { IISAN_ATTN_CASE(2); }
     else if (S <= 64) { IISAN_ATTN_CASE(4); }
     else if (S <= 128) { IISAN_ATTN_CASE(8); }

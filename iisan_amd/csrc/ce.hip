@@ -838,8 +838,8 @@ extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
 static uint64_t ce_token(int64_t bs, int32_t S, int fused) {
     return 0xCE00000000000000ull | ((uint64_t)(bs & 0xFFFFFFFFll) << 16) | ((uint64_t)(S & 0xFF) << 8) | (uint64_t)(fused ? 2 : 1);
 }
-extern "C" void iisan_set_ce_fast(int32_t on) { g_ce_fast = on; }
-extern "C" void iisan_set_ce_debug(int32_t bits) { g_ce_dbg = bits; }        // ablation bits of the fused row pass (timing only)
+IISAN_DEV_KNOB(ce_fast, g_ce_fast);
+IISAN_DEV_KNOB(ce_debug, g_ce_dbg);        // ablation bits of the fused row pass (timing only)
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,

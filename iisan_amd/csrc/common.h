@@ -41,6 +41,25 @@ void iisan_set_error(const char* fmt, ...);
 
 #define IISAN_LAUNCH_OK() IISAN_HIP_OK(hipGetLastError())
 
+// ---- development switches (dev.cpp; include/iisan_hip.h DEV section) ------------------------------------------------------
+// A kernel file's process-wide route / ablation variable becomes reachable by name through iisan_dev_set / iisan_dev_get:
+//     static int g_ln_fold = 2;   IISAN_DEV_KNOB(ln_fold, g_ln_fold);
+// the value at registration time is the library default (iisan_dev_reset, iisan_dev_state).
+struct IisanDevKnob {
+    const char* name;
+    int64_t def;
+    int64_t (*get)();
+    void (*set)(int64_t);
+};
+int iisan_dev_register(const IisanDevKnob& k);
+#define IISAN_DEV_KNOB(NAME, VAR)                                                                                \
+    static const int iisan_dev_reg_##NAME = iisan_dev_register(IisanDevKnob{                                     \
+        #NAME, (int64_t)(VAR), [] { return (int64_t)(VAR); }, [](int64_t v) { VAR = (decltype(VAR))v; }})
+// ... with a side effect behind the store (SET is a statement using the new value `v`)
+#define IISAN_DEV_KNOB_FN(NAME, VAR, SET)                                                                        \
+    static const int iisan_dev_reg_##NAME = iisan_dev_register(IisanDevKnob{                                     \
+        #NAME, (int64_t)(VAR), [] { return (int64_t)(VAR); }, [](int64_t v) { SET; }})
+
 #define IISAN_TRY(expr)                                                                                          \
     do {                                                                                                         \
         int _r = (expr);                                                                                         \

@@ -137,9 +137,9 @@ int check_common(int hidden, int layers, int heads, int mlp, int n_taps, const i
 
 }  // namespace
 
-extern "C" void iisan_set_full_blocks(int32_t on) { g_full_blocks = on; }
-extern "C" void iisan_set_resid32(int32_t on) { g_resid32 = on; }
-extern "C" void iisan_set_ln_fold(int32_t on) { g_ln_fold = on; }
+IISAN_DEV_KNOB(full_blocks, g_full_blocks);
+IISAN_DEV_KNOB(resid32, g_resid32);
+IISAN_DEV_KNOB(ln_fold, g_ln_fold);
 static int vit_fold_layers(const iisan_vit_weights* w) {
     return (!g_resid32 && g_ln_fold && w->dtype16 == IISAN_F16) ? w->layers : 0;
 }

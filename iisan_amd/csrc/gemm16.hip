@@ -258,17 +258,18 @@ static int g_auto_staggered = 1;
 // auto policy: which staggered kernel takes the production shapes — 1 = gemm16_h256.hip (half-slot tile boundary: same-box
 // A/B of tools/gemm_var.py over three boxes: QKV +1..4 %, O +1 %, FC1 +-0, FC2 +3..4 %; bit-identical results), 0 = gemm16_s256.hip.
 static int g_auto_h256 = 1;
-extern "C" void iisan_set_gemm16_h256(int32_t on) { g_auto_h256 = on; }
+IISAN_DEV_KNOB(gemm16_h256, g_auto_h256);
 // 1: the staggered kernel starts its workgroups up to ~one tile time apart on the short-K products with store-heavy
 // epilogues (QKV scatter, FC1 GELU), so the CUs' store bursts stop coinciding (tools/gemm_time.py: QKV 963 -> 988, FC1 900 ->
 // 913 TF; O -2 %, FC2 -7 %: not applied there).  Knob for the A/B (tools/desync_ab.py).
 static int g_desync = 0;
-extern "C" void iisan_set_gemm16_desync(int32_t on) { g_desync = on; }
-extern "C" void iisan_set_gemm16_variant(int v) { g_variant = v; }
+IISAN_DEV_KNOB(gemm16_desync, g_desync);
+IISAN_DEV_KNOB(gemm16_variant, g_variant);
 // tile walk of gemm16_h256 (bench knob): c = -1 auto policy, 0 = row-major tile list, > 0 = panels of c column tiles walked down
 // sub-slabs of h row tiles (h <= 0: the XCD's whole slab)
 static int g_walk_c = -1, g_walk_h = 0;
-extern "C" void iisan_set_gemm16_walk(int32_t c, int32_t h) { g_walk_c = c; g_walk_h = h; }
+IISAN_DEV_KNOB(gemm16_walk_c, g_walk_c);
+IISAN_DEV_KNOB(gemm16_walk_h, g_walk_h);
 
 int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0, "gemm16: empty problem M=%lld N=%d K=%d", (long long)a.M, a.N, a.K);

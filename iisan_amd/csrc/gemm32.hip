@@ -862,11 +862,9 @@ int g_accum_via_scratch = 1;       // 0: weight-gradient split-K sums by atomics
 // launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
 // before split-K stops adding slices
 static int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
-extern "C" void iisan_set_gemm32_accum_scratch(int32_t on) { g_accum_via_scratch = on; }
-extern "C" void iisan_set_gemm32_tuning(int32_t tm_thresh, int32_t splitk_target) {
-    g_tm_thresh = tm_thresh > 0 ? tm_thresh : 512;
-    g_splitk_target = splitk_target > 0 ? splitk_target : 1024;
-}
+IISAN_DEV_KNOB(gemm32_accum_scratch, g_accum_via_scratch);
+IISAN_DEV_KNOB_FN(gemm32_tm_thresh, g_tm_thresh, g_tm_thresh = v > 0 ? (int)v : 512);
+IISAN_DEV_KNOB_FN(gemm32_splitk_target, g_splitk_target, g_splitk_target = v > 0 ? (int)v : 1024);
 
 template <int FLAGS>
 int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bool deep, hipStream_t s) {
@@ -894,13 +892,13 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bo
 
 // 1 (default): K = 64 products with a wide N and a plain epilogue take gemm32_k64_kernel; 0: the tiled kernel.  Test / bench knob.
 static int g_use_k64 = 1, g_use_dw = 1;
-extern "C" void iisan_set_gemm32_dw(int32_t on) { g_use_dw = on; }
-extern "C" void iisan_set_gemm32_k64(int32_t on) { g_use_k64 = on; }
+IISAN_DEV_KNOB(gemm32_dw, g_use_dw);
+IISAN_DEV_KNOB(gemm32_k64, g_use_k64);
 
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
 
 static int g_use_n64f = 1;
-extern "C" void iisan_set_gemm32_n64f(int32_t on) { g_use_n64f = on; }
+IISAN_DEV_KNOB(gemm32_n64f, g_use_n64f);
 bool gemm32_n64f_ok(const N64FDesc* d, int n) {
     if (!g_use_n64f || n < 1 || n > 3) return false;
     for (int i = 0; i < n; ++i) {
@@ -983,7 +981,7 @@ static bool k64_shape_ok(const Gemm32Prob& q) {
            (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.resid | (uintptr_t)q.bias) & 15) == 0;
 }
 static int g_use_k64_gate = 1;
-extern "C" void iisan_set_gemm32_k64_gate(int32_t on) { g_use_k64_gate = on; }
+IISAN_DEV_KNOB(gemm32_k64_gate, g_use_k64_gate);
 bool gemm32_k64_gate_ok(const Gemm32Prob* probs, const K64Gate* gates, int nprob) {
     if (!g_use_k64 || !g_use_k64_gate || nprob < 1 || nprob > 4) return false;
     for (int i = 0; i < nprob; ++i) {

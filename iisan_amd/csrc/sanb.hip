@@ -405,8 +405,9 @@ static void fill(SanbTower& t, const SanbTowerDesc& d) {
 }
 
 static int g_sanb_debug = 0, g_sanb_stagger = 0, g_sanb_persist = 1;
-extern "C" void iisan_set_sanb_debug(int32_t bits) { g_sanb_debug = bits; }
-extern "C" void iisan_set_sanb_schedule(int32_t persistent, int32_t stagger_units) { g_sanb_persist = persistent; g_sanb_stagger = stagger_units; }
+IISAN_DEV_KNOB(sanb_debug, g_sanb_debug);
+IISAN_DEV_KNOB(sanb_persistent, g_sanb_persist);
+IISAN_DEV_KNOB(sanb_stagger, g_sanb_stagger);
 
 template <bool BWD>
 static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) {

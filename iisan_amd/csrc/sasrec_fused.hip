@@ -616,8 +616,8 @@ __global__ __launch_bounds__(256) void sasrec_reduce_kernel(const float* __restr
 // The fused path covers the production configuration; anything else stays on the per-operator launches of sasrec.hip.
 static int g_sasrec_fused = 1;
 static long long* g_sasrec_stamps = nullptr;
-extern "C" void iisan_set_sasrec_stamps(void* p) { g_sasrec_stamps = (long long*)p; }
-extern "C" void iisan_set_sasrec_fused(int32_t on) { g_sasrec_fused = on; }
+IISAN_DEV_KNOB(sasrec_stamps, g_sasrec_stamps);      // device pointer of a cycle-stamp buffer (tools/sasrec_stamps.py), 0 = none
+IISAN_DEV_KNOB(sasrec_fused, g_sasrec_fused);
 bool sasrec_fused_shape_ok(const iisan_sasrec_cfg* cfg) {       // (the workspace is sized by this alone: the knob only picks kernels)
     return cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&
            (cfg->heads == 1 || cfg->heads == 2 || cfg->heads == 4) && (FR / cfg->seq) * cfg->heads * cfg->seq <= 192 && cfg->blocks >= 1 && cfg->blocks <= 8;

@@ -426,15 +426,13 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 
 }  // namespace
 
-extern "C" void iisan_set_sanb_fused(int32_t on) { g_use_sanb = on; }
+IISAN_DEV_KNOB(sanb_fused, g_use_sanb);
 
 void gemm_x3_set_min_flops(double f);     // negative = the library default (split.hip: X3_DEFAULT_MIN_FLOPS, 4 GFLOP)
 // 0 = off, 1 = library default (the state of a process that never calls this knob), 2 = every product whose shape allows
 // it (tests: the small golden fixtures then run through the split-operand path too)
-extern "C" void iisan_set_x3(int32_t mode) {
-    g_use_x3 = mode != 0;
-    gemm_x3_set_min_flops(mode == 2 ? 0.0 : -1.0);
-}
+static int g_x3_mode = 1;
+IISAN_DEV_KNOB_FN(x3, g_x3_mode, (g_x3_mode = (int)v, g_use_x3 = v != 0, gemm_x3_set_min_flops(v == 2 ? 0.0 : -1.0)));
 
 extern "C" size_t iisan_side_net_ws_bytes(const iisan_side_cfg* cfg, int64_t M) {
     Plan p;

@@ -84,7 +84,10 @@ class _PackedEncoder:
 class PackedVit(_PackedEncoder):
     """ViT weights resident in HBM in kernel layout (canonical names of `iisan_amd.weights`)."""
 
-    def __init__(self, w: Dict[str, torch.Tensor], cfg: VitConfig, device="cuda", dtype16: int = _lib.IISAN_F16):
+    def __init__(self, w: Dict[str, torch.Tensor], cfg: VitConfig, device="cuda", dtype16: int = _lib.IISAN_F16,
+                 keep_masters: bool = False):
+        """keep_masters: keep the fp32 originals of qkv_w / fc1_w resident after the one-time LayerNorm fold (tests that fold per call);
+        by default they are released once `folded` is written — the executor only reads `folded` (~200 MB for ViT-B)."""
         super().__init__(w, device, dtype16)
         self.cfg = cfg
         s = _lib.VitWeights()
@@ -103,6 +106,16 @@ class PackedVit(_PackedEncoder):
             with torch.cuda.device(self.device):
                 _lib.check(lib.iisan_vit_fold_layernorm(C.byref(s), _ptr(self._folded), nbytes, _stream()), "iisan_vit_fold_layernorm")
             s.folded = _ptr(self._folded)
+            # the fold ran on the stream current at construction; forwards may be issued on any other stream later: make the
+            # folded set visible to all of them once, here (a one-time wait at pack time, never on the step)
+            torch.cuda.current_stream(self.device).synchronize()
+            if not keep_masters:
+                masters = set()
+                for l in range(cfg.layers):
+                    L = s.layer[l]
+                    masters.update((L.qkv_w32, L.fc1_w32))
+                    L.qkv_w32 = L.fc1_w32 = None
+                self._keep = [t for t in self._keep if _ptr(t) not in masters]
 
     def forward_taps(self, images: torch.Tensor, tap_layers: Sequence[int], chunk_items: int = 0) -> torch.Tensor:
         """images fp32 [M,C,R,R] (normalised) or uint8 [M,C,R,R] (raw pixels, normalised on the device) -> fp32

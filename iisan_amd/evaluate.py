@@ -89,16 +89,47 @@ def _pack_users(seqs: Sequence[Sequence[int]], histories: Sequence[Sequence[int]
     return torch.from_numpy(tok), torch.from_numpy(lm), torch.from_numpy(hist), torch.from_numpy(tgt.astype(np.int32))
 
 
+HIST_MAX = 256      # exclusion-list entries per user that iisan_score_rank takes in one launch (csrc/score.hip: MAXH)
+
+
+def _rank_long_history(prec_u: torch.Tensor, item_emb: torch.Tensor, history: Sequence[int], target: int) -> int:
+    """Exact rank of ONE user whose exclusion list exceeds HIST_MAX entries, from launches of `iisan_score_rank` alone.
+    With R(H) the kernel's rank under exclusion set H and T0 = {target} if the target is itself excluded (its score is then -inf in
+    every pass, metrics.py:204-205) else {}:   R(H) = R(T0) + sum_i [R(H_i + T0) - R(T0)]   over disjoint chunks H_i of H - T0 —
+    each excluded item changes the count by the same integer whichever pass it sits in, because the target's effective score and
+    every item's score bits (csrc/score.hip: one MFMA chain per score) are the same in all passes."""
+    dev = prec_u.device
+    uniq = list(dict.fromkeys(int(c) for c in history if int(c) != 0))        # order kept, duplicates and padding dropped
+    t0 = [target] if target in set(uniq) else []
+    rest = [c for c in uniq if c != target]
+    step = HIST_MAX - len(t0)
+    chunks = [t0] + [rest[i:i + step] + t0 for i in range(0, len(rest), step)]
+    hist = torch.zeros((len(chunks), HIST_MAX), dtype=torch.int32)
+    for i, ch in enumerate(chunks):
+        hist[i, :len(ch)] = torch.tensor(ch, dtype=torch.int32)
+    r = ops.score_rank(prec_u.expand(len(chunks), -1).contiguous(), item_emb, hist.to(dev),
+                       torch.full((len(chunks),), target, dtype=torch.int32, device=dev)).to(torch.int64).cpu()
+    if bool((r < 1).any()):
+        return -1                                      # invalid target: reported like the kernel does
+    return int(r[0] + (r[1:] - r[0]).sum())
+
+
 @torch.no_grad()
 def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[int]], histories: Sequence[Sequence[int]],
                    max_seq_len: int, batch: int = 1024, rank: int = 0, world: int = 1) -> torch.Tensor:
     """1-based rank of every user's target (int32 [U], identical on all ranks).  `eval_seqs[u]` = history + target
     (`eval_seq`), `histories[u]` = items to exclude (`user_history`, metrics.py:204-205)."""
     U = len(eval_seqs)
+    # iisan_score_rank keeps a user's exclusion list in LDS (include/iisan_hip.h: hist_stride <= 256).  Users with longer lists (the
+    # reference masks histories of any length, metrics.py:198-207) keep their first 256 entries in the batched pass and are re-ranked
+    # exactly by `_rank_long_history` below — a few more launches of the same kernel, no other arithmetic (ADVICE r4).
+    long_users = [u for u in range(U) if len(histories[u]) > HIST_MAX]
+    if long_users:
+        histories = list(histories)
+        full = {u: histories[u] for u in long_users}
+        for u in long_users:
+            histories[u] = full[u][:HIST_MAX]
     hs = max(1, max(len(h) for h in histories))
-    if hs > 256:       # iisan_score_rank keeps a user's exclusion list in LDS (include/iisan_hip.h: hist_stride <= 256)
-        raise ValueError(f"evaluate_ranks: the longest exclusion list has {hs} items; iisan_score_rank takes at most 256 per user "
-                         "(Scientific: <= 10 train items per user)")
     idx = dp.sequential_shard(U, rank, world, batch) if world > 1 else list(range(U))
     tok, lm, hist, tgt = _pack_users([eval_seqs[i] for i in idx], [histories[i] for i in idx], max_seq_len, hs)
     dev = item_emb.device
@@ -109,7 +140,11 @@ def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[i
         t, m = tok[i:i + batch].to(dev), lm[i:i + batch].to(dev)
         x = item_emb[t]                                            # == com_dense(cat(tables[tokens])), metrics.py:214
         prec = model.user_encoder(x, m, None)[:, -1].contiguous()   # metrics.py:216
-        out.append(ops.score_rank(prec, item_emb, hist[i:i + batch].to(dev), tgt[i:i + batch].to(dev)))
+        r = ops.score_rank(prec, item_emb, hist[i:i + batch].to(dev), tgt[i:i + batch].to(dev))
+        for k in range(i, min(i + batch, len(idx))):
+            if long_users and idx[k] in full:
+                r[k - i] = _rank_long_history(prec[k - i:k - i + 1], item_emb, full[idx[k]], int(tgt[k]))
+        out.append(r)
     model.train(was_training)
     ranks = torch.cat(out)
     ranks = dp.gather_concat(ranks, U) if world > 1 else ranks

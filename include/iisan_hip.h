@@ -291,6 +291,57 @@ int iisan_gather_taps(int32_t store_dtype, const void* table, int64_t rows, cons
 /* f32 -> 16-bit conversion helper used when packing weights */
 int iisan_cast16(int32_t dtype16, const float* src, void* dst, int64_t n, void* stream);
 
+/* Kernel-level entry points of the encoder GEMM's epilogue families (tests/test_gpu_primitives.py, tools/gemm_*.py): the
+ * products behind HF ViTLayer's QKV / O / FC1 / FC2 dense layers as the executors launch them. */
+/* iisan_gemm16 with explicit leading dimensions (mode 0 / 1) */
+int iisan_gemm16_ld(int32_t dtype16, int32_t mode, const void* A, const void* W, const float* bias, void* out, int64_t M,
+                    int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, void* stream);
+/* fp16 operands, fp32 output, optional split-K (ksplit > 1: atomic accumulation into a caller-zeroed out) */
+int iisan_gemm16_f32(const void* A, const void* W, float* out, int64_t M, int32_t N, int32_t K, int32_t ksplit,
+                     void* stream);
+/* LN(x) W^T + b with the LayerNorm applied in the epilogue: A = x [M,K] fp16 (the residual stream), W / bias = the folded set
+ * (iisan_fold_ln_weights), rowstat [ceil(M/256)*256] = rstd per row (NULL: plain product); mode 1 (GELU) or 4 (head-major QKV,
+ * S tokens per item, N / 192 heads) */
+int iisan_gemm16_lna(int32_t mode, const void* A, const void* W, const float* bias, void* out, const float* rowstat, int64_t M,
+                     int32_t N, int32_t K, int32_t S, void* stream);
+/* gamma-folded, centred weights of one LayerNorm -> Linear pair: Wf[n,:] = fp16(g * W[n,:] - mean_k(g * W[n,:])), bf = b_lin + W beta
+ * (w32 != 0: W is the fp32 master, else the 16-bit copy) */
+int iisan_fold_ln_weights(const void* W, int32_t w32, const float* bias, const float* g, const float* b, void* Wf, float* bf,
+                          int32_t N, void* stream);
+/* x16 <- fp16(x16 + A W^T + bias) in place (fp16 residual stream, N <= 1024) + per-64-column-slice row sums / sums of squares into
+ * rowpart [N/64][Mpad][2]; rows m with m % S == 0 (CLS rows) receive the delta alone */
+int iisan_gemm16_stream(const void* A, const void* W, const float* bias, void* x16, float* rowpart, int64_t M, int32_t N,
+                        int32_t K, int32_t S, void* stream);
+/* rowpart -> rstd per row; folds the CLS rows' deltas into their fp32 stream xc [items, N] */
+int iisan_stream_stats_finalize(const float* rowpart, int32_t nslots, int64_t Mpad, void* x16, float* xc, float* rstat,
+                                float eps, int64_t items, int32_t Ttok, void* stream);
+/* host-side predicate (no device touched): does the persistent 256x256 kernel take this product? */
+int32_t iisan_gemm16_h256_applicable(int32_t mode, int64_t M, int32_t N, int32_t K, int32_t qkv_S, int32_t qkv_heads,
+                                     int32_t qkv_which0);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DEV section — process-wide development switches and measurement hooks.  NOT part of the product contract: a
+ * product process calls none of these and the library defaults ARE the product routes.  Every other entry point
+ * above is stateless and re-entrant per stream; these are the only process-global state the library has.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Named switches (kernel-family selection for golden-pinned reference runs, ablation bits, A/B routes).  Names are
+ * registered by the kernel files (csrc/common.h: IISAN_DEV_KNOB); iisan_dev_state(buf, cap, 1) lists them all.
+ * set: 0 or IISAN_EBADSHAPE (unknown name).  get: the value, INT64_MIN for an unknown name.
+ * state: writes "name=value,..." of every switch NOT at its library default (all != 0: every switch) and returns the
+ * length needed; "" means the product routes are in force.  reset: every switch back to its default. */
+int32_t iisan_dev_set(const char* name, int64_t value);
+int64_t iisan_dev_get(const char* name);
+size_t iisan_dev_state(char* buf, size_t cap, int32_t all);
+void iisan_dev_reset(void);
+/* Per-launch HIP-event timing of one kernel class on the launching stream (bench.py's roofline.dominant_kernel):
+ * cls 0 = off, 1 = the 16-bit encoder GEMM, 2 = the f32-matrix-core family of the trainable side.  only_stream: with on != 0
+ * only launches on `stream` are timed.  collect: waits for the recorded events, returns the launch count, fills total
+ * milliseconds and FLOPs; last_bytes: algorithmic bytes of the launches of the last collect. */
+void iisan_timing_enable(int32_t cls);
+void iisan_timing_only_stream(void* stream, int32_t on);
+int64_t iisan_timing_collect(double* total_ms, double* total_flops);
+double iisan_timing_last_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

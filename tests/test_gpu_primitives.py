@@ -33,7 +33,7 @@ def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
     """variant 1 = 128x128 v1 kernel, 2 = persistent lock-step 256x256 kernel, 3 = persistent staggered 256x256 kernel
     (16-bit epilogues only); 2 and 3 fall back when the shape does not qualify (N % 256 != 0, K < 128)."""
     M, N, K = shape
-    lib.iisan_set_gemm16_variant(variant)
+    _lib.dev_set("gemm16_variant", variant)
     g = torch.Generator().manual_seed(M * 7 + N + K + mode)
     # asymmetric, non-identity operands (catches transposed / permuted fragment layouts)
     A = (torch.randn(M, K, generator=g) * 0.5).to(T16[dt])
@@ -55,7 +55,7 @@ def test_gemm16_vs_torch(lib, variant, dt, mode, shape):
     _lib.check(lib.iisan_gemm16(dt, mode, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
                                 rp.data_ptr() if rp is not None else None, M, N, K, _stream()), "gemm16")
     torch.cuda.synchronize()
-    lib.iisan_set_gemm16_variant(0)
+    _lib.dev_set("gemm16_variant", 0)
     got = out.cpu().double()
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
@@ -82,10 +82,10 @@ def test_gemm16_h256_race_screen_against_the_s256_kernel(lib, shape):
         W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
         bias = torch.randn(N, generator=g, device="cuda") * 0.3
         for v in (3, 4):
-            lib.iisan_set_gemm16_variant(v)
+            _lib.dev_set("gemm16_variant", v)
             out[v].fill_(float("nan"))
             _lib.check(lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out[v].data_ptr(), None, M, N, K, _stream()), "gemm16")
-        lib.iisan_set_gemm16_variant(0)
+        _lib.dev_set("gemm16_variant", 0)
         torch.cuda.synchronize()
         assert torch.isfinite(out[4]).all(), f"iteration {it}: rows not written"
         assert torch.equal(out[3], out[4]), f"iteration {it}: {(out[3].float() - out[4].float()).abs().max().item():.3e}"
@@ -93,7 +93,7 @@ def test_gemm16_h256_race_screen_against_the_s256_kernel(lib, shape):
 
 @pytest.mark.parametrize("shape", [(2304, 5000, 2304, 256, 4), (6000, 6000, 1536, 192, 1), (2048, 2050, 3072, 128, 0)])
 def test_gemm16_h256_tile_walks_are_bit_identical(lib, shape):
-    """Round 4: `gemm16_h256_kernel` walks the tile space per XCD in panels (`iisan_set_gemm16_walk(c, h)`: c column tiles wide, sub-slabs of
+    """Round 4: `gemm16_h256_kernel` walks the tile space per XCD in panels (dev switch `gemm16_walk` (c, h): c column tiles wide, sub-slabs of
     h row tiles; the auto policy uses 3 x 16 for N >= 1536, M >= 32768).  The walk only changes WHICH workgroup computes a tile and when:
     every walk must give the bits of the row-major list — panels that do not divide the tile row (c = 2, 5 on 9 / 6 / 12 column tiles), a
     last sub-slab shorter than h, slabs of unequal height (row tiles not a multiple of 8), a ragged last row tile, fewer tiles than CUs
@@ -106,8 +106,8 @@ def test_gemm16_h256_tile_walks_are_bit_identical(lib, shape):
     ref = None
     try:
         for c, h in ((0, 0), (1, 1), (2, 3), (3, 16), (5, 7), (8, 2), (4, 0)):
-            lib.iisan_set_gemm16_variant(4)
-            lib.iisan_set_gemm16_walk(c, h)
+            _lib.dev_set("gemm16_variant", 4)
+            (_lib.dev_set("gemm16_walk_c", c), _lib.dev_set("gemm16_walk_h", h))
             if mode == 4:      # head-major QKV needs the executor's argument set: through the public entry the plain epilogue stands in
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
                 _lib.check(lib.iisan_gemm16(0, 0, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None, M, N, K, _stream()), "gemm16")
@@ -125,8 +125,8 @@ def test_gemm16_h256_tile_walks_are_bit_identical(lib, shape):
             else:
                 assert torch.equal(out, ref), (c, h, (out.float() - ref.float()).abs().max().item())
     finally:
-        lib.iisan_set_gemm16_variant(0)
-        lib.iisan_set_gemm16_walk(-1, 0)
+        _lib.dev_set("gemm16_variant", 0)
+        (_lib.dev_set("gemm16_walk_c", -1), _lib.dev_set("gemm16_walk_h", 0))
 
 
 def _ln_fold_case(M, N, K, row_mean, seed):
@@ -194,7 +194,7 @@ def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
     Mp = x16.shape[0]
     outs = []
     try:
-        lib.iisan_set_gemm16_variant(4)
+        _lib.dev_set("gemm16_variant", 4)
         for rep in range(3):
             out = torch.zeros(Mp, N, dtype=torch.float16, device="cuda")
             _lib.check(lib.iisan_gemm16_lna(mode, x16.data_ptr(), Wf.data_ptr(), bf.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, N, K, S, _stream()), "gemm16_lna")
@@ -203,7 +203,7 @@ def test_gemm16_h256_layernorm_epilogue_every_element_every_run(lib, case):
         ln16 = ln32.half().contiguous()
         _lib.check(lib.iisan_gemm16_lna(mode, ln16.data_ptr(), W.data_ptr(), b.data_ptr(), img.data_ptr(), None, M, N, K, S, _stream()), "gemm16 (image)")
     finally:
-        lib.iisan_set_gemm16_variant(0)
+        _lib.dev_set("gemm16_variant", 0)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     worst = 0.0
@@ -239,7 +239,7 @@ def test_gemm16_h256_stream_epilogue_adds_into_the_stream_and_leaves_row_sums(li
     Mp = A.shape[0]
     runs = []
     try:
-        lib.iisan_set_gemm16_variant(4)
+        _lib.dev_set("gemm16_variant", 4)
         for rep in range(3):
             x = x0.clone(); xc = xc0.clone()
             part = torch.zeros(N // 64, Mp, 2, device="cuda"); rstat = torch.zeros(Mp, device="cuda")
@@ -248,7 +248,7 @@ def test_gemm16_h256_stream_epilogue_adds_into_the_stream_and_leaves_row_sums(li
             _lib.check(lib.iisan_stream_stats_finalize(part.data_ptr(), N // 64, Mp, x.data_ptr(), xc.data_ptr(), rstat.data_ptr(), 1e-6, items, S, _stream()), "finalize")
             runs.append((xg, part, x, xc, rstat))
     finally:
-        lib.iisan_set_gemm16_variant(0)
+        _lib.dev_set("gemm16_variant", 0)
     torch.cuda.synchronize()
     for r in runs[1:]:
         assert all(torch.equal(a, b2) for a, b2 in zip(r, runs[0]))
@@ -308,7 +308,10 @@ def _attn_ref(qkv, key_bias, items, S, heads):
 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("case", [(3, 197, 12, False), (5, 30, 12, True), (4, 5, 12, False), (3, 8, 2, True),
-                                  (2, 64, 3, False), (2, 100, 2, True)])
+                                  (2, 64, 3, False), (2, 100, 2, True),
+                                  # 14 key tiles (S = 209..224): ADVICE r4 — the V^T row stride of the 13-tile kernel (212) was applied to
+                                  # this instantiation too: neighbouring head dims overlapped and the last row ran into the key limits
+                                  (2, 224, 2, False), (2, 209, 3, True), (1, 208, 2, True)])
 def test_attention16_vs_torch(lib, dt, case):
     items, S, heads, masked = case
     g = torch.Generator().manual_seed(S * 13 + heads)

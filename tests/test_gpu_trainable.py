@@ -81,9 +81,9 @@ def test_gemm32_vs_torch(lib, case):
 def sanb_mode(lib, request):
     """2 = a SANB step runs as one fused launch per direction (`csrc/sanb.hip`); 0 = fusion kernel + separate GEMM launches.  (The
     product default, 1, picks by the number of item slots: fused below 4,096.)"""
-    lib.iisan_set_sanb_fused(request.param)
+    _lib.dev_set("sanb_fused", request.param)
     yield request.param
-    lib.iisan_set_sanb_fused(1)
+    _lib.dev_set("sanb_fused", 1)
 
 
 @pytest.fixture
@@ -91,9 +91,9 @@ def x3_mode(lib, request):
     """Route of the side network's large Linear layers (`csrc/sidenet.hip:gemm_group`): 1 = product default (split-operand
     fp16 MFMA GEMM for products of >= 8 GFLOP, f32 matrix cores below), 2 = split-operand GEMM for EVERY product whose
     shape allows it — so the small reference goldens pin that path too — 0 = f32 matrix cores only."""
-    lib.iisan_set_x3(request.param)
+    _lib.dev_set("x3", request.param)
     yield request.param
-    lib.iisan_set_x3(1)
+    _lib.dev_set("x3", 1)
 
 
 @pytest.mark.parametrize("sanb_mode", [2, 0], indirect=True)
@@ -383,6 +383,61 @@ def test_score_rank_kernel_shapes_histories_and_ties(case):
     assert n_close <= max(2, U // 20)
 
 
+def test_exclusion_lists_longer_than_one_launch_takes_are_ranked_exactly():
+    """`evaluate_ranks` rejected users with more than 256 excluded items; the reference masks histories of any length
+    (`metrics.py:198-207`).  `evaluate._rank_long_history` re-ranks such a user from launches of the same kernel alone
+    (R(H) = R(T0) + sum_i [R(H_i + T0) - R(T0)]): must equal (1) the single-launch rank whenever the list DOES fit (bit-for-bit the
+    same arithmetic, so equality is exact — ties included), and (2) the counting definition in fp64 for lists of 300 / 700 / 1,500
+    items, with duplicates, zeros, and the target inside its own history."""
+    from iisan_amd import evaluate
+    g = torch.Generator().manual_seed(77)
+    n1 = 5000
+    item = torch.randn(n1, 64, generator=g)
+    item[7] = item[3]
+    prec = torch.randn(6, 64, generator=g).cuda()
+    item_d = item.cuda()
+    # (1) lists that fit one launch, chunked artificially small: the decomposition itself
+    old = evaluate.HIST_MAX
+    try:
+        for u, (H, t) in enumerate([(40, 7), (200, 1234), (256, 99)]):
+            h = torch.randint(0, n1, (H,), generator=g, dtype=torch.int32)
+            if u == 1:
+                h[5] = t                                   # the target inside its own history
+            one = ops.score_rank(prec[u:u + 1], item_d, h.view(1, -1).cuda(), torch.tensor([t], dtype=torch.int32).cuda()).item()
+            evaluate.HIST_MAX = 256
+            assert evaluate._rank_long_history(prec[u:u + 1], item_d, h.tolist(), t) == one
+            for cap in (16, 37):
+                # (chunks of `cap` entries inside 256-wide launches: only the chunking changes)
+                uniq = list(dict.fromkeys(int(c) for c in h.tolist() if c != 0))
+                t0 = [t] if t in uniq else []
+                rest = [c for c in uniq if c != t]
+                rows = [t0] + [rest[i:i + cap] + t0 for i in range(0, len(rest), cap)]
+                hh = torch.zeros(len(rows), 256, dtype=torch.int32)
+                for i, ch in enumerate(rows):
+                    hh[i, :len(ch)] = torch.tensor(ch, dtype=torch.int32)
+                r = ops.score_rank(prec[u:u + 1].expand(len(rows), -1).contiguous(), item_d, hh.cuda(),
+                                   torch.full((len(rows),), t, dtype=torch.int32).cuda()).cpu().long()
+                assert int(r[0] + (r[1:] - r[0]).sum()) == one, (u, cap)
+    finally:
+        evaluate.HIST_MAX = old
+    # (2) lists that do not fit, against the definition
+    sc = prec.cpu().double() @ item.double().t()
+    for u, (H, t, in_hist) in enumerate([(300, 4321, False), (700, 17, True), (1500, 2500, False)], start=3):
+        h = torch.randint(0, n1, (H,), generator=g).tolist()
+        h[0] = h[-1]
+        if in_hist:
+            h[H // 2] = t
+        else:
+            h = [c for c in h if c != t]
+        got = evaluate._rank_long_history(prec[u:u + 1], item_d, h, t)
+        s = sc[u].clone()
+        s[torch.tensor([c for c in h if c > 0])] = -float("inf")
+        ids = torch.arange(n1)
+        ahead = (s > s[t]) | ((s == s[t]) & (ids < t))
+        ahead[0] = False
+        assert got == 1 + int(ahead.sum()), (u, got, 1 + int(ahead.sum()))
+
+
 def _drop_factors(seed, site, n, p):
     """numpy re-implementation of drop_scale() in iisan_amd/csrc/common.h."""
     M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -442,7 +497,7 @@ def test_sasrec_one_launch_kernels_match_the_oracle_and_the_per_operator_launche
     counter-based generator produces) at the Cached batch size (bs = 1024: 256 workgroups of four sequences, the reducer's long
     sums), at a batch whose last workgroup is ragged (130 = 32 x 4 + 2), other sequence lengths / head counts (G = 48 / S sequences
     per workgroup: 6 at S = 7, 3 at S = 16) — and S = 20, which the fused path does not take (per-operator launches).  And the
-    two implementations against each other (`iisan_set_sasrec_fused`): same values to fp32 rounding, either backward after either
+    two implementations against each other (dev switch `sasrec_fused`): same values to fp32 rounding, either backward after either
     forward (they share the workspace slots).  Reference: `Code_Uncached/model/encoders.py:60-65`, `modules.py:6-96`."""
     E, L, seed = 64, 2, 987654321
     g = torch.Generator().manual_seed(B + S)
@@ -472,13 +527,13 @@ def test_sasrec_one_launch_kernels_match_the_oracle_and_the_per_operator_launche
         for fwd_fused, bwd_fused in ((1, 1), (0, 0), (1, 0), (0, 1)):
             params = [P[pre + k].cuda().requires_grad_(True) for k in order]
             xd = x.cuda().requires_grad_(True)
-            lib.iisan_set_sasrec_fused(fwd_fused)
+            _lib.dev_set("sasrec_fused", fwd_fused)
             y = ops.SasrecFn.apply(cfg, xd, lm.cuda(), *params)
-            lib.iisan_set_sasrec_fused(bwd_fused)
+            _lib.dev_set("sasrec_fused", bwd_fused)
             (y * w.cuda()).sum().backward()
             res[(fwd_fused, bwd_fused)] = [y.detach().cpu(), xd.grad.cpu()] + [t.grad.cpu() for t in params]
     finally:
-        lib.iisan_set_sasrec_fused(1)
+        _lib.dev_set("sasrec_fused", 1)
     ref = [yo.detach(), xo.grad] + [Po[pre + k].grad for k in order]
     names = ["y", "dx"] + order
     for key, got in res.items():
@@ -803,7 +858,7 @@ def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(l
     ids, lm = b.ids.view(-1).cuda(), b.log_mask.cuda()
     g = torch.Generator(device="cuda").manual_seed(9)
     raw = [(torch.randn(n + 1, 7, d, generator=g, device="cuda") * 0.25).half() for d in (1024, 8192)]
-    lib.iisan_set_x3(2)               # every product whose shape allows it on the split-operand route (bs = 128: M = 1,408)
+    _lib.dev_set("x3", 2)               # every product whose shape allows it on the split-operand route (bs = 128: M = 1,408)
     out = {}
     try:
         for store in ("fp16", "fp32"):
@@ -819,7 +874,7 @@ def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(l
             loss.backward()
             out[store] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
     finally:
-        lib.iisan_set_x3(1)
+        _lib.dev_set("x3", 1)
     (l16, g16), (l32, g32) = out["fp16"], out["fp32"]
     assert torch.equal(l16, l32), (l16.item(), l32.item())
     for k in g16:
@@ -834,7 +889,7 @@ def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
     reference's formula (`model.py:81-104`, as restated in oracle.inbatch_logits) evaluated in fp64 on the device —
     the oracle itself is CPU-sized; its formula is checked against the reference goldens at small sizes."""
     from iisan_amd import synth
-    lib.iisan_set_ce_fast(ce_fast)        # 1 = product default (fused online-softmax row pass), 2 = separate FWD / DPREC row passes, 0 = generic kernel
+    _lib.dev_set("ce_fast", ce_fast)        # 1 = product default (fused online-softmax row pass), 2 = separate FWD / DPREC row passes, 0 = generic kernel
     bs, S, E = 1024, 10, 64
     b = synth.scientific_batch(bs=bs, seed=77, res=2, words=2, dup_items=True)     # ids / log_mask / pop_prob (tiny content)
     g = torch.Generator().manual_seed(5)
@@ -847,7 +902,7 @@ def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
         loss = ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
         loss.backward()
     finally:
-        lib.iisan_set_ce_fast(1)
+        _lib.dev_set("ce_fast", 1)
     gs, gp = score.grad.clone(), prec.grad.clone()
 
     sd, pd = score.detach().double().requires_grad_(True), prec.detach().double().requires_grad_(True)
@@ -871,13 +926,16 @@ def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
     _close(gp, pd.grad, 2e-4, 1e-9, "d_prec at bs=1024")
 
 
-@pytest.mark.parametrize("variant", [0, 3])
-def test_production_size_step_meets_the_north_star_tolerance(lib, variant):
+@pytest.mark.parametrize("variant,full_blocks", [(0, 0), (3, 0), (4, 0), (4, 1)])
+def test_production_size_step_meets_the_north_star_tolerance(lib, variant, full_blocks):
     """The north-star tolerance at PRODUCTION size: ViT-B/16 + BERT-base (12 layers each, seeded weights), the default
-    IISAN side network (7 taps per tower), bs = 2 sequences = 22 item slots, fp16 encoder operands, dead-work pruning
-    on — HIP loss within 1e-3 relative of the fp32 CPU oracle's, the item embeddings of real slots within 1e-3 and the
-    seven taps per tower inside the encoder budget.  variant 0 = the product's dispatch, 3 = every encoder GEMM forced
-    onto the staggered 256x256 kernel that the bs=128 headline runs on (`csrc/gemm16.hip:launch_gemm16`)."""
+    IISAN side network (7 taps per tower), bs = 2 sequences = 22 item slots, fp16 encoder operands — HIP loss within 1e-3
+    relative of the fp32 CPU oracle's, the item embeddings of real slots within 1e-3 and the seven taps per tower inside the
+    encoder budget.  variant 0 = the product's dispatch (22 items go to the 128x128 kernels), 3 = every encoder GEMM forced onto
+    the staggered 256x256 kernel (`gemm16_s256.hip`, the race-screen twin), 4 = forced onto `gemm16_h256.hip` WITH the library's
+    default ln_fold = 2 — LayerNorm in the QKV / FC1 epilogues, residual adds in the O / FC2 epilogues: the kernel set and route
+    the bs = 128 headline runs on (`csrc/gemm16.hip:launch_gemm16`, `csrc/encoders.hip`), with the CLS-only last block (0) and
+    with every block on every token as the headline runs it (full_blocks = 1)."""
     vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
     b = synth.scientific_batch(bs=2, seed=2024, lengths=[11, 4])
     args = helpers.make_args(drop_rate=0.0)
@@ -887,16 +945,14 @@ def test_production_size_step_meets_the_north_star_tolerance(lib, variant):
     model.train()
     ids = b.ids.view(-1)
     need = [0, 2, 4, 6, 8, 10, 12]
-    try:
-        lib.iisan_set_gemm16_variant(variant)
+    assert _lib.dev_get("ln_fold") == 2
+    with _lib.dev(gemm16_variant=variant, full_blocks=full_blocks):
         loss = model(ids.cuda(), b.images.cuda(), b.text.cuda(), b.log_mask.cuda(), 0)
         with torch.no_grad():
             score = model.score_embs(b.images.cuda(), b.text.cuda(), ids.cuda()).cpu()
             enc = model.mm_encoder
             hc = enc.cv_encoder.forward_taps(b.images.cuda(), need).cpu()
             ht = enc.bert_encoder.forward_taps(b.text.cuda(), need).cpu()
-    finally:
-        lib.iisan_set_gemm16_variant(0)
     with torch.no_grad():
         tc = O.vit_cls_taps(b.images, vw, weights.VIT_BASE)
         tt = O.bert_cls_taps(b.text, bw, weights.BERT_BASE)
@@ -911,6 +967,65 @@ def test_production_size_step_meets_the_north_star_tolerance(lib, variant):
         ec = ((hc[:, k] - tc[:, l]).norm() / tc[:, l].norm()).item()
         et = ((ht[:, k] - tt[:, l]).norm() / tt[:, l].norm()).item()
         assert ec < 1.5e-3 and et < 1.5e-3, (l, ec, et)
+
+
+def test_default_dispatch_at_bs128_against_the_oracle_directly():
+    """the bench headline's own shape and route — 1,408 item slots (bs = 128, Scientific-shaped lengths) through the
+    DEFAULT dispatch (persistent 256x256 kernels, LayerNorm / residual adds in their epilogues, the production attention grid) —
+    held to the fp32 CPU ORACLE itself, not to another kernel family: (1) the seven CLS taps per tower of EVERY slot (encoder rows
+    are independent, `Code_Uncached/model/encoders.py:29-31`; all padding slots share one input, so the oracle encodes ~600 real
+    slots + 1 padding slot: first, middle and last row tiles, padding and real slots alike) inside the tap budget, no single slot
+    off; (2) the bs = 128 training loss within 1e-3 of `O.model_loss_from_taps` fed the 1,408 oracle taps — with the CLS-only last
+    block (the library default) and with every block on every token (the headline)."""
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    b = synth.scientific_batch(bs=128, seed=12345)
+    args = helpers.make_args(drop_rate=0.0)
+    model = helpers.build_model(args, synth.SCI_ITEM_NUM, b.pop_prob, vw, weights.VIT_BASE, bw, weights.BERT_BASE, cached=False)
+    P = weights.make_trainable_params(seed=99)
+    helpers.load_trainables(model, P)
+    model.train()
+    ids = b.ids.view(-1)
+    need = [0, 2, 4, 6, 8, 10, 12]
+    M = ids.numel()
+    assert M == 1408
+    # oracle taps: every real slot + ONE padding slot (zero image, zero title, all-zero attention mask), 32 items at a time
+    real = torch.nonzero(ids != 0).view(-1)
+    pad = torch.nonzero(ids == 0).view(-1)
+    assert real.numel() > 400 and pad.numel() > 400
+    assert not b.images[pad].any() and not b.text[pad].any()
+    enc_rows = torch.cat([real, pad[:1]])
+    oc = torch.empty(M, 13, 768)
+    ot = torch.empty(M, 13, 768)
+    with torch.no_grad():
+        for i in range(0, enc_rows.numel(), 32):
+            r = enc_rows[i:i + 32]
+            oc[r] = O.vit_cls_taps(b.images[r], vw, weights.VIT_BASE)
+            ot[r] = O.bert_cls_taps(b.text[r], bw, weights.BERT_BASE)
+        oc[pad] = oc[pad[0]]
+        ot[pad] = ot[pad[0]]
+        layers = O.side_layer_list(args.side_adapter_vit_list, False)
+        ref, aux = O.model_loss_from_taps(b.ids, oc, ot, b.log_mask, b.pop_prob, P, layers)
+    assert _lib.dev_state() == "", "this test is about the library's default routes"
+    dev_b = b.to("cuda")
+    for full_blocks in (0, 1):
+        with _lib.dev(full_blocks=full_blocks):
+            loss = model(ids.cuda(), dev_b.images, dev_b.text, dev_b.log_mask, 0)
+            with torch.no_grad():
+                enc = model.mm_encoder
+                hc = enc.cv_encoder.forward_taps(dev_b.images, need).cpu()
+                ht = enc.bert_encoder.forward_taps(dev_b.text, need).cpu()
+        rel = abs(loss.item() - ref.item()) / abs(ref.item())
+        assert rel < 1e-3, f"bs=128 loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e} (full_blocks={full_blocks})"
+        assert torch.equal(hc[:, 0], oc[:, 0]) or ((hc[:, 0] - oc[:, 0]).norm() / oc[:, 0].norm()).item() < 1e-6
+        for k, l in enumerate(need[1:], 1):
+            ec = ((hc[:, k] - oc[:, l]).norm() / oc[:, l].norm()).item()
+            et = ((ht[:, k] - ot[:, l]).norm() / ot[:, l].norm()).item()
+            assert ec < 1.5e-3 and et < 1.5e-3, (full_blocks, l, ec, et)
+            # per slot: a mis-addressed tile, a lost row statistic or a stale stream row corrupts a few slots, not the norm.  Over
+            # first / middle / last row tiles, real and padding slots alike
+            pc = (hc[:, k] - oc[:, l]).norm(dim=1) / oc[:, l].norm(dim=1)
+            pt = (ht[:, k] - ot[:, l]).norm(dim=1) / ot[:, l].norm(dim=1)
+            assert pc.max().item() < 4e-3 and pt.max().item() < 4e-3, (full_blocks, l, pc.max().item(), int(pc.argmax()), pt.max().item(), int(pt.argmax()))
 
 
 def test_padding_slots_have_exactly_zero_influence_on_the_loss():
@@ -1022,13 +1137,13 @@ def test_backward_follows_the_route_its_forward_took_not_the_knobs_of_the_moment
     def ce(flip_from, flip_to):
         score = torch.randn(bs * (S + 1), E, generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
         prec = torch.randn(bs * S, E, generator=torch.Generator().manual_seed(8)).cuda().requires_grad_(True)
-        lib.iisan_set_ce_fast(flip_from)
+        _lib.dev_set("ce_fast", flip_from)
         try:
             loss = ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
-            lib.iisan_set_ce_fast(flip_to)
+            _lib.dev_set("ce_fast", flip_to)
             loss.backward()
         finally:
-            lib.iisan_set_ce_fast(1)
+            _lib.dev_set("ce_fast", 1)
         return loss.detach().clone(), score.grad.clone(), prec.grad.clone()
 
     base = ce(1, 1)
@@ -1068,14 +1183,14 @@ def test_backward_follows_the_route_its_forward_took_not_the_knobs_of_the_moment
     bsz, S_ = bb_.log_mask.shape
     tc = taps_cv.view(bsz, S_ + 1, 13, 768).cuda()
     tt = taps_tx.view(bsz, S_ + 1, 13, 768).cuda()
-    lib.iisan_set_x3(1)
+    _lib.dev_set("x3", 1)
     try:
         cv, (text, mm) = model.mm_encoder(tc, tt)
-        lib.iisan_set_x3(2)
+        _lib.dev_set("x3", 2)
         with pytest.raises(_lib.IisanHipError, match="routing"):
             (cv.sum() + text.sum() + mm.sum()).backward()
     finally:
-        lib.iisan_set_x3(1)
+        _lib.dev_set("x3", 1)
 
 
 def test_cached_step_on_a_poisoned_heap_is_finite_and_its_weight_gradients_reproducible(lib):
@@ -1194,11 +1309,11 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
     g = torch.Generator(device="cuda").manual_seed(3)
     out = {}
     for alt in (False, True):
-        lib.iisan_set_x3(2 if (alt and route == "x3") else 0)
-        lib.iisan_set_sanb_fused(2 if (alt and route == "sanb") else 0)
-        lib.iisan_set_gemm32_dw(0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
-        lib.iisan_set_gemm32_k64_gate(0 if (route == "gate" and not alt) else 1)      # "gate": fusion backward folded into the dF product
-        lib.iisan_set_gemm32_n64f(0 if (route == "n64f" and not alt) else 1)          # "n64f": fusion folded into the down projection
+        _lib.dev_set("x3", 2 if (alt and route == "x3") else 0)
+        _lib.dev_set("sanb_fused", 2 if (alt and route == "sanb") else 0)
+        _lib.dev_set("gemm32_dw", 0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
+        _lib.dev_set("gemm32_k64_gate", 0 if (route == "gate" and not alt) else 1)      # "gate": fusion backward folded into the dF product
+        _lib.dev_set("gemm32_n64f", 0 if (route == "n64f" and not alt) else 1)          # "n64f": fusion folded into the down projection
         try:
             kw = dict(drop_rate=0.0, adapter_activation="GELU")
             if versa:
@@ -1220,11 +1335,11 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
             loss.backward()
             out[alt] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
         finally:
-            lib.iisan_set_x3(1)
-            lib.iisan_set_sanb_fused(1)
-            lib.iisan_set_gemm32_dw(1)
-            lib.iisan_set_gemm32_k64_gate(1)
-            lib.iisan_set_gemm32_n64f(1)
+            _lib.dev_set("x3", 1)
+            _lib.dev_set("sanb_fused", 1)
+            _lib.dev_set("gemm32_dw", 1)
+            _lib.dev_set("gemm32_k64_gate", 1)
+            _lib.dev_set("gemm32_n64f", 1)
     (l0, g0), (l1, g1) = out[False], out[True]
     assert abs(l1.item() - l0.item()) <= 2e-5 * abs(l0.item()), (l0.item(), l1.item())
     differ = 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the two attention kernels (iisan_set_attn_debug bit 5: 0 = register-prefetch kernel, two workgroups per CU, the
+"""Same-process A/B of the two attention kernels (dev switch attn_debug bit 5: 0 = register-prefetch kernel, two workgroups per CU, the
 product; 32 = no prefetch, three workgroups per CU) on the ViT (197 tokens) and BERT (30 tokens) shapes of the bs = 128 step:
 device time per launch, output equality."""
 import os, sys, time, torch
@@ -15,7 +15,7 @@ for name, S, bias in (("vit", 197, False), ("bert", 30, True)):
         kb = torch.zeros(items, S, device="cuda"); kb[:, 20:] = -1.0; kb[5] = -1.0
     out = {}
     for dbg in (0, 32):
-        lib.iisan_set_attn_debug(dbg)
+        _lib.dev_set("attn_debug", dbg)
         ctx = torch.full((items * S, heads * 64), float("nan"), device="cuda", dtype=torch.float16)
         lib.iisan_attention16(0, qkv.data_ptr(), kb.data_ptr() if bias else None, ctx.data_ptr(), items, S, heads, st)
         torch.cuda.synchronize()
@@ -24,7 +24,7 @@ for name, S, bias in (("vit", 197, False), ("bert", 30, True)):
     print(f"{name}: new vs old kernel max |d| {d:.3e}, finite {torch.isfinite(out[0]).all().item()}", flush=True)
     for r in range(3):
         for dbg in (0, 32):
-            lib.iisan_set_attn_debug(dbg)
+            _lib.dev_set("attn_debug", dbg)
             for _ in range(3): lib.iisan_attention16(0, qkv.data_ptr(), kb.data_ptr() if bias else None, ctx.data_ptr(), items, S, heads, st)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): lib.iisan_attention16(0, qkv.data_ptr(), kb.data_ptr() if bias else None, ctx.data_ptr(), items, S, heads, st)
@@ -38,11 +38,11 @@ for r in range(2):
     for pf in (0, 32):
         row = []
         for hpw in (1, 2, 3, 4, 6):
-            lib.iisan_set_attn_debug(pf | (hpw << 8))
+            _lib.dev_set("attn_debug", pf | (hpw << 8))
             for _ in range(3): lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
             torch.cuda.synchronize()
             row.append(f"hpw {hpw}: {(time.perf_counter() - t0) / 20 * 1e6:.0f}")
         print(f"  round {r} {'no-prefetch/3wg' if pf else 'prefetch/2wg'}: " + "  ".join(row), flush=True)
-lib.iisan_set_attn_debug(0)
+_lib.dev_set("attn_debug", 0)

@@ -11,7 +11,7 @@ ctx = torch.empty(items * S, heads * 64, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
 flops = items * heads * 4.0 * S * S * 64
 for name, dbg in (("full", 0), ("no Vt write", 1), ("no K write", 16), ("no store", 8), ("no LDS writes, no store", 1 + 16 + 8)):
-    lib.iisan_set_attn_debug(dbg)
+    _lib.dev_set("attn_debug", dbg)
     for _ in range(2):
         lib.iisan_attention16(0, qkv.data_ptr(), None, ctx.data_ptr(), items, S, heads, st)
     torch.cuda.synchronize()
@@ -21,4 +21,4 @@ for name, dbg in (("full", 0), ("no Vt write", 1), ("no K write", 16), ("no stor
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print(f"{name:16s} {dt*1e6:8.1f} us  ({flops/dt/1e12:.0f} TF-equivalent)")
-lib.iisan_set_attn_debug(0)
+_lib.dev_set("attn_debug", 0)

@@ -14,7 +14,7 @@ ids, lm, pop = b.ids.view(-1).cuda(), b.log_mask.float().cuda(), b.pop_prob.floa
 score = (torch.randn(bs * (S + 1), E, generator=g) * 0.3).cuda()
 prec = (torch.randn(bs * S, E, generator=g) * 0.3).cuda()
 for bits, name in ((0, "full"), (1, "no logits MFMAs"), (2, "no d_prec MFMAs"), (3, "no MFMAs")):
-    lib.iisan_set_ce_debug(bits)
+    _lib.dev_set("ce_debug", bits)
     for _ in range(3):
         ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
     torch.cuda.synchronize()
@@ -24,4 +24,4 @@ for bits, name in ((0, "full"), (1, "no logits MFMAs"), (2, "no d_prec MFMAs"), 
         ops.InbatchCeFn.apply(ids, score, prec, lm, pop)
     e1.record(); torch.cuda.synchronize()
     print(f"{name:20s} forward (prep + fused row pass + reduce) {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
-lib.iisan_set_ce_debug(0)
+_lib.dev_set("ce_debug", 0)

@@ -15,7 +15,7 @@ a = bench.parse(["--no-cpu-baseline", "--no-secondary", "--no-check"])
 unc = bench.Uncached(a, lib, torch.device("cuda", 0), 0, 1)
 for rnd in range(4):
     for on in (0, 1):
-        lib.iisan_set_gemm16_desync(on)
+        _lib.dev_set("gemm16_desync", on)
         ln = unc.line(8, 2, "fp16", False, headline=False)
         print(f"round {rnd} desync={on}: {ln['ms_per_step']:.2f} ms/step  gemm16 {ln['roofline']['achieved']:.0f} TF", flush=True)
-lib.iisan_set_gemm16_desync(0)
+_lib.dev_set("gemm16_desync", 0)

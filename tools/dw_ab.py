@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the weight-gradient kernel (gemm32_dw_kernel, knob iisan_set_gemm32_dw) on the Cached (bs = 1024) and Versa (bs = 128)
+"""A/B of the weight-gradient kernel (gemm32_dw_kernel, knob dev switch gemm32_dw) on the Cached (bs = 1024) and Versa (bs = 128)
 steps, one process, interleaved rounds.  Usage on the GPU box: python tools/dw_ab.py"""
 import contextlib
 import io
@@ -28,6 +28,6 @@ def run(versa, steps=20):
 for versa in (False, True):
     for rnd in range(3):
         for mode in (0, 1):
-            lib.iisan_set_gemm32_dw(mode)
+            _lib.dev_set("gemm32_dw", mode)
             print(f"{'versa ' if versa else 'cached'} round {rnd} dw={mode}: {run(versa):.3f} ms/step", flush=True)
-lib.iisan_set_gemm32_dw(1)
+_lib.dev_set("gemm32_dw", 1)

@@ -18,10 +18,10 @@ for argv in (["--cached", "fp32"], ["--cached", "fp16", "--versa"]):
     a = bench.parse(argv)
     for via in (1, 0):
         for target in (128, 256, 384, 512, 1024):
-            lib.iisan_set_gemm32_accum_scratch(via)
-            lib.iisan_set_gemm32_tuning(512, target)
+            _lib.dev_set("gemm32_accum_scratch", via)
+            (_lib.dev_set("gemm32_tm_thresh", 512), _lib.dev_set("gemm32_splitk_target", target))
             with contextlib.redirect_stdout(io.StringIO()):
                 ln = bench.cached_line(a, lib, dev, 0, 1, 10, 3)
             print(f"{' '.join(argv):24s} {'scratch' if via else 'atomics'} split-K target {target:5d}: {ln['ms_per_step']:.3f} ms/step", flush=True)
-lib.iisan_set_gemm32_accum_scratch(1)
-lib.iisan_set_gemm32_tuning(512, 1024)
+_lib.dev_set("gemm32_accum_scratch", 1)
+(_lib.dev_set("gemm32_tm_thresh", 512), _lib.dev_set("gemm32_splitk_target", 1024))

@@ -15,7 +15,7 @@ from iisan_amd import _lib  # noqa: E402
 lib = _lib.load()
 import torch  # noqa: E402
 
-KNOB = "iisan_set_" + (sys.argv[1] if len(sys.argv) > 1 else "gemm32_k64_gate")
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "gemm32_k64_gate"
 MODES = [int(x) for x in sys.argv[2:]] or [0, 1]
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -31,6 +31,6 @@ def run(extra, steps=20):
 for name, extra in (("cached", ["fp32"]), ("dedup ", ["fp32", "--dedup"]), ("versa ", ["fp16", "--versa"])):
     for rnd in range(3):
         for mode in MODES:
-            getattr(lib, KNOB)(mode)
-            print(f"{name} round {rnd} {KNOB[10:]}={mode}: {run(extra):.3f} ms/step", flush=True)
-getattr(lib, KNOB)(1)
+            _lib.dev_set(KNOB, mode)
+            print(f"{name} round {rnd} {KNOB}={mode}: {run(extra):.3f} ms/step", flush=True)
+_lib.dev_set(KNOB, 1)

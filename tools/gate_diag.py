@@ -9,7 +9,7 @@ from iisan_amd import _lib, factory as helpers
 from oracle import iisan_oracle as O
 lib = _lib.load()
 for r32 in (1, 0):
-    lib.iisan_set_resid32(r32)
+    _lib.dev_set("resid32", r32)
     z, vw, bw, b, P = gio.e2e_small_inputs("e2e_inter", modality="inter")
     args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8, modality="inter")
     model = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
@@ -28,4 +28,4 @@ for r32 in (1, 0):
                 g, go = p.grad.cpu().double(), Pg[n].grad.double()
                 print(f"resid32={r32} oracle {str(dtype)[6:]}: {n}: |g| {go.norm().item():.3e} abs err {(g-go).norm().item():.3e} rel {((g-go).norm()/go.norm()).item():.2e}")
         if dtype == torch.float64: print("loss hip", loss.item(), "oracle", lo.item())
-lib.iisan_set_resid32(0)
+_lib.dev_set("resid32", 0)

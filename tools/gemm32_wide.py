@@ -8,7 +8,7 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 import itertools
 for M, mode in itertools.product((1408, 11264), (0, 1)):
-    lib.iisan_set_gemm32_k64(mode)
+    _lib.dev_set("gemm32_k64", mode)
     print("k64 mode", mode)
     for name, N, K, ta, tb in [("up  [M,64]x[N,64]^T", 8192, 64, 0, 0), ("up  [M,64]x[N,64]^T", 1024, 64, 0, 0),
                                ("dF  [M,64]x[64,N]", 8192, 64, 0, 1)]:

@@ -13,8 +13,8 @@ walk = (sys.argv[3] if len(sys.argv) > 3 else "0:0").split(":")
 M = 277376
 st = torch.cuda.current_stream().cuda_stream
 shapes = [("qkv", 2304, 768, 0), ("o", 768, 768, 0), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 0)]
-lib.iisan_set_gemm16_variant(4)
-lib.iisan_set_gemm16_walk(int(walk[0]), int(walk[1]))
+_lib.dev_set("gemm16_variant", 4)
+(_lib.dev_set("gemm16_walk_c", int(walk[0])), _lib.dev_set("gemm16_walk_h", int(walk[1])))
 which = os.environ.get("PAD_WHICH", "awo")      # which leading dimensions get the pad
 data = {}
 for name, N, K, mode in shapes:

@@ -39,19 +39,19 @@ for name, N, mode in (("qkv", 2304, 4), ("fc1", 3072, 1)):
     out_a = torch.zeros(Mp, N, device="cuda", dtype=torch.float16); out_b = torch.zeros_like(out_a)
 
     def run_img(it):
-        lib.iisan_set_gemm16_variant(4)
+        _lib.dev_set("gemm16_variant", 4)
         for _ in range(it):
             if mode == 4:
                 assert lib.iisan_gemm16_lna(4, ln16.data_ptr(), W.data_ptr(), b.data_ptr(), out_a.data_ptr(), None, M, N, K, S, st) == 0, lib.iisan_last_error()
             else:
                 assert lib.iisan_gemm16(0, 1, ln16.data_ptr(), W.data_ptr(), b.data_ptr(), out_a.data_ptr(), None, M, N, K, st) == 0
-        lib.iisan_set_gemm16_variant(0)
+        _lib.dev_set("gemm16_variant", 0)
 
     def run_lna(it):
-        lib.iisan_set_gemm16_variant(4)
+        _lib.dev_set("gemm16_variant", 4)
         for _ in range(it):
             assert lib.iisan_gemm16_lna(mode, x16.data_ptr(), Wf.data_ptr(), bf.data_ptr(), out_b.data_ptr(), rowstat.data_ptr(), M, N, K, S, st) == 0, lib.iisan_last_error()
-        lib.iisan_set_gemm16_variant(0)
+        _lib.dev_set("gemm16_variant", 0)
 
     run_img(1); run_lna(1); torch.cuda.synchronize()
     # every element against fp32 arithmetic, three launches (a rare-lane glitch shows as a handful of elements off by O(0.1))

@@ -10,7 +10,7 @@ W = (torch.randn(N, K, device="cuda") * 0.05).half()
 b = torch.randn(N, device="cuda")
 out = torch.empty(M + 256, N, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
-lib.iisan_set_gemm16_variant(var)
+_lib.dev_set("gemm16_variant", var)
 for _ in range(3):
     lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
 torch.cuda.synchronize()

@@ -14,10 +14,10 @@ W = (torch.randn(N, K, device="cuda") * 0.05).half()
 b = torch.randn(N, device="cuda")
 out = torch.empty(M + 256, N, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
-lib.iisan_set_gemm16_variant(var)
+_lib.dev_set("gemm16_variant", var)
 if os.environ.get("GEMM_WALK"):          # "c:h" — tile walk of gemm16_h256
     c, h = os.environ["GEMM_WALK"].split(":")
-    lib.iisan_set_gemm16_walk(int(c), int(h))
+    (_lib.dev_set("gemm16_walk_c", int(c)), _lib.dev_set("gemm16_walk_h", int(h)))
 for _ in range(6):
     lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
 torch.cuda.synchronize()

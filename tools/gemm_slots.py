@@ -14,7 +14,7 @@ out = torch.empty(M + 256, N, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
 CASES = [(1, "no-epilogue"), (0, "full")] if len(sys.argv) < 2 else [(int(a), f"debug {a}") for a in sys.argv[1:]]
 for dbg, label in CASES:
-    lib.iisan_set_gemm16_variant(3 + ((dbg | 16) << 8))
+    _lib.dev_set("gemm16_variant", 3 + ((dbg | 16) << 8))
     for _ in range(2):
         lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
         torch.cuda.synchronize()
@@ -29,4 +29,4 @@ for dbg, label in CASES:
             prev_m_end = m_end
         print(f" group {'AB'[g]}: (time from previous M end to this R end, wait at R barrier, M work):")
         print("   " + " ".join(f"({a},{b_},{c})" for a, b_, c in rows))
-lib.iisan_set_gemm16_variant(0)
+_lib.dev_set("gemm16_variant", 0)

@@ -23,7 +23,7 @@ F = ["Rlo", "bar", "Mlo", "bar", "Rhi+E", "bar", "Mhi"]
 labels = [f"F.{x}" for x in F] + [f"m{k}.{x}" for k in range(1, nk - 1) for x in ("R", "bar", "M")] + [f"L.{x}" for x in F]
 per_tile = len(labels)
 for dbg in ([int(a) for a in sys.argv[1:]] or [1, 0]):
-    lib.iisan_set_gemm16_variant(4 + ((dbg | 16) << 8))
+    _lib.dev_set("gemm16_variant", 4 + ((dbg | 16) << 8))
     for _ in range(2):
         lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
         torch.cuda.synchronize()
@@ -36,4 +36,4 @@ for dbg in ([int(a) for a in sys.argv[1:]] or [1, 0]):
             d = [x[i + 1] - x[i] for i in range(per_tile)]
             print(f" group {'AB'[g]} tile {tile}: total {x[-1] - x[0]}")
             print("   " + " ".join(f"{l}={v}" for l, v in zip(labels, d)))
-lib.iisan_set_gemm16_variant(0)
+_lib.dev_set("gemm16_variant", 0)

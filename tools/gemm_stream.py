@@ -25,7 +25,7 @@ for name, K in (("o", 768), ("fc2", 3072)):
     xc0 = torch.randn(items, N, device="cuda", generator=g) * 1.5
     part = torch.zeros(N // 64, Mp, 2, device="cuda")
     rstat = torch.zeros(Mp, device="cuda")
-    lib.iisan_set_gemm16_variant(4 | (int(os.environ.get('DBG', 0)) << 8))
+    _lib.dev_set("gemm16_variant", 4 | (int(os.environ.get('DBG', 0)) << 8))
     for rep in range(3):
         x = x0.clone(); xc = xc0.clone(); part.zero_(); rstat.zero_()
         assert lib.iisan_gemm16_stream(A.data_ptr(), W.data_ptr(), b.data_ptr(), x.data_ptr(), part.data_ptr(), M, N, K, S, st) == 0, lib.iisan_last_error()
@@ -72,4 +72,4 @@ for name, K in (("o", 768), ("fc2", 3072)):
             x.copy_(x0)
             row.append(f"{nm} {dt * 1e6:7.1f} us" + (f" ({2.0 * M * N * K / dt / 1e12:5.0f} TF)" if nm != "finalize" else ""))
         print(f"{name} round {r}: " + "   ".join(row), flush=True)
-    lib.iisan_set_gemm16_variant(0)
+    _lib.dev_set("gemm16_variant", 0)

@@ -17,7 +17,7 @@ for name, N, K, mode in shapes:
     res = {}
     XV = [3 + ((8 + (u << 8)) << 8) for u in (2, 4, 5, 6, 8)]
     for var in [1, 2, 3, 3 + 256, 3 + 1024] + XV:
-        lib.iisan_set_gemm16_variant(var)
+        _lib.dev_set("gemm16_variant", var)
         for _ in range(2):
             lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), out.data_ptr() if mode == 2 else None, M, N, K, st)
         torch.cuda.synchronize()
@@ -29,4 +29,4 @@ for name, N, K, mode in shapes:
         dt = (time.perf_counter() - t0) / it
         res[var] = (dt * 1e3, 2.0 * M * N * K / dt / 1e12)
     print(f"{name:4s} M={M} N={N} K={K}: v1 {res[1][0]:.3f} ms {res[1][1]:.0f} TF | p256 {res[2][0]:.3f} ms {res[2][1]:.0f} TF | s256 {res[3][0]:.3f} ms {res[3][1]:.0f} TF | s256 no-epilogue {res[259][1]:.0f} TF | s256 desync {res[1027][0]:.3f} ms {res[1027][1]:.0f} | xcd-phase " + " ".join(f"{res[v][1]:.0f}" for v in XV))
-lib.iisan_set_gemm16_variant(0)
+_lib.dev_set("gemm16_variant", 0)

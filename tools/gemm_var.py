@@ -25,11 +25,11 @@ for name, N, K, mode in shapes:
 
 def run(name, N, K, mode, v, iters):
     A, W, b, out = data[name]
-    lib.iisan_set_gemm16_variant(v)
+    _lib.dev_set("gemm16_variant", v)
     for _ in range(iters):
         rc = lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
         assert rc == 0, lib.iisan_last_error()
-    lib.iisan_set_gemm16_variant(0)
+    _lib.dev_set("gemm16_variant", 0)
 
 
 # bit-identity of the variants

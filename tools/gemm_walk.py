@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process A/B of tile walks of gemm16_h256 (iisan_set_gemm16_walk) on the ViT-B encoder shapes (M = 277,376 token rows):
+"""Same-process A/B of tile walks of gemm16_h256 (dev switch gemm16_walk) on the ViT-B encoder shapes (M = 277,376 token rows):
     python tools/gemm_walk.py "0:0,3:0,3:16,4:16" [rounds] [shapes, default qkv,fc1] [debug bits, e.g. 64 = nt stores]
 Each walk is c:h (panel width in column tiles : sub-slab height in row tiles; 0:0 = the row-major list).  A "+64" suffix on a walk
 adds debug bits for that arm (e.g. 4:16+64).  Prints TFLOP/s per shape and round (interleaved) and checks bit-identity against the first walk."""
@@ -33,13 +33,13 @@ for name, N, K, mode in shapes:
 def run(name, N, K, mode, arm, iters):
     A, W, b, out = data[name]
     c, h, dbg = arm
-    lib.iisan_set_gemm16_variant(4 | (dbg << 8))
-    lib.iisan_set_gemm16_walk(c, h)
+    _lib.dev_set("gemm16_variant", 4 | (dbg << 8))
+    (_lib.dev_set("gemm16_walk_c", c), _lib.dev_set("gemm16_walk_h", h))
     for _ in range(iters):
         rc = lib.iisan_gemm16(0, mode, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), None, M, N, K, st)
         assert rc == 0, lib.iisan_last_error()
-    lib.iisan_set_gemm16_variant(0)
-    lib.iisan_set_gemm16_walk(-1, 0)
+    _lib.dev_set("gemm16_variant", 0)
+    (_lib.dev_set("gemm16_walk_c", -1), _lib.dev_set("gemm16_walk_h", 0))
 
 
 for name, N, K, mode in shapes:

@@ -29,12 +29,12 @@ def run(versa, steps=20):
 modes = [int(x) for x in sys.argv[1:]] or [0, 1]
 for rnd in range(3):
     for mode in modes:
-        lib.iisan_set_gemm32_k64(mode)
+        _lib.dev_set("gemm32_k64", mode)
         print(f"round {rnd} versa k64={mode}: {run(True):.3f} ms/step", flush=True)
-lib.iisan_set_sanb_fused(0)
+_lib.dev_set("sanb_fused", 0)
 for rnd in range(2):
     for mode in modes:
-        lib.iisan_set_gemm32_k64(mode)
+        _lib.dev_set("gemm32_k64", mode)
         print(f"round {rnd} cached (unfused SANB) k64={mode}: {run(False):.3f} ms/step", flush=True)
-lib.iisan_set_sanb_fused(1)
-lib.iisan_set_gemm32_k64(1)
+_lib.dev_set("sanb_fused", 1)
+_lib.dev_set("gemm32_k64", 1)

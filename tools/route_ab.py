@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the fused SANB launches (iisan_set_sanb_fused 2 = always) against the unfused route (0) on the Cached step (bs = 1024),
+"""A/B of the fused SANB launches (dev switch sanb_fused 2 = always) against the unfused route (0) on the Cached step (bs = 1024),
 all slots and distinct ids only; one process, interleaved rounds.  (Headline: IISAN_DEV_KNOBS="sanb_fused=2|0" python bench.py.)
 Usage on the GPU box: python tools/route_ab.py"""
 import contextlib
@@ -29,6 +29,6 @@ def run(extra, steps=20):
 for extra in ([], ["--dedup"]):
     for rnd in range(3):
         for fused in (2, 0):
-            lib.iisan_set_sanb_fused(fused)
+            _lib.dev_set("sanb_fused", fused)
             print(f"cached {' '.join(extra):8s} round {rnd} fused={fused}: {run(extra):.3f} ms/step", flush=True)
-lib.iisan_set_sanb_fused(1)
+_lib.dev_set("sanb_fused", 1)

@@ -16,14 +16,14 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 a = bench.parse(["--cached", "fp32"])
 for bits, name in ((0, "full"), (1, "no narrow product"), (2, "no wide product"), (3, "no products (HBM phases only)")):
-    lib.iisan_set_sanb_debug(bits)
+    _lib.dev_set("sanb_debug", bits)
     with contextlib.redirect_stdout(io.StringIO()):
         ln = bench.cached_line(a, lib, dev, 0, 1, 10, 3)
     print(f"{name:32s} {ln['ms_per_step']:.3f} ms/step", flush=True)
-lib.iisan_set_sanb_debug(0)
+_lib.dev_set("sanb_debug", 0)
 for persist, units in ((0, 0), (1, 0), (1, 2), (1, 4), (1, 6), (1, 8), (1, 12)):
-    lib.iisan_set_sanb_schedule(persist, units)
+    (_lib.dev_set("sanb_persistent", persist), _lib.dev_set("sanb_stagger", units))
     with contextlib.redirect_stdout(io.StringIO()):
         ln = bench.cached_line(a, lib, dev, 0, 1, 10, 3)
     print(f"persistent={persist} stagger={units:2d}  {ln['ms_per_step']:.3f} ms/step", flush=True)
-lib.iisan_set_sanb_schedule(1, 0)
+(_lib.dev_set("sanb_persistent", 1), _lib.dev_set("sanb_stagger", 0))

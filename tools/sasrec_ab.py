@@ -14,7 +14,7 @@ order = ops.sasrec_param_order(L)
 
 
 def run(B, p, fused, iters=0):
-    lib.iisan_set_sasrec_fused(fused)
+    _lib.dev_set("sasrec_fused", fused)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, S, E, generator=g).cuda().requires_grad_(True)
     lm = (torch.rand(B, S, generator=g) > 0.3).float(); lm[:, -1] = 1; lm = lm.cuda()
@@ -47,7 +47,7 @@ for B in ((37, 128, 1024) if len(sys.argv) < 2 else ()):
         names = ["y", "dx"] + order
         wi = max(range(len(r1)), key=lambda i: ((r1[i] - r0[i]).norm() / (r0[i].norm() + 1e-12)).item())
         print(f"B={B} p={p}: fused vs per-operator worst rel {worst:.2e} ({names[wi]}); fwd {tf1:.3f} vs {tf0:.3f} ms, fwd+bwd-autograd {tb1:.3f} vs {tb0:.3f} ms", flush=True)
-lib.iisan_set_sasrec_fused(1)
+_lib.dev_set("sasrec_fused", 1)
 
 # which of the two is right where they differ?  both against the fp32 oracle (the fp64 one keeps q.k beside the -1e9 mask that fp32 absorbs) at B = 1024 (eval mode)
 from oracle import iisan_oracle as O
@@ -67,4 +67,4 @@ for fused in (1, 0):
     errs = [((a.cpu().double() - b.double()).norm() / (b.norm() + 1e-30)).item() for a, b in zip(r, ref)]
     wi = max(range(len(errs)), key=lambda i: errs[i])
     print(f"B=1024 fused={fused} vs fp32 oracle (the fp64 one keeps q.k beside the -1e9 mask that fp32 absorbs): worst rel {errs[wi]:.2e} ({names[wi]}), median {sorted(errs)[len(errs)//2]:.2e}; y {errs[0]:.2e} dx {errs[1]:.2e}")
-lib.iisan_set_sasrec_fused(1)
+_lib.dev_set("sasrec_fused", 1)

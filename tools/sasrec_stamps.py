@@ -15,10 +15,10 @@ x = torch.randn(B, S, E, device="cuda"); lm = torch.ones(B, S, device="cuda")
 st = torch.zeros(64, dtype=torch.int64, device="cuda")
 cfg = ops.make_sasrec_cfg(S, E, H, L, 0.0, 1)
 for it in range(3):
-    lib.iisan_set_sasrec_stamps(st.data_ptr())
+    _lib.dev_set("sasrec_stamps", st.data_ptr() or 0)
     y = ops.SasrecFn.apply(cfg, x, lm, *params)
     torch.cuda.synchronize()
-    lib.iisan_set_sasrec_stamps(None)
+    _lib.dev_set("sasrec_stamps", None or 0)
     t = st.cpu().tolist()
     n = max(i for i, v in enumerate(t) if v) + 1
     print("run", it, "total cycles", t[n - 1] - t[0], "stages:", [t[i + 1] - t[i] for i in range(n - 1)])

@@ -13,7 +13,7 @@ st = torch.cuda.current_stream().cuda_stream
 for B in (128, 1024):
     for p in (0.0, 0.1):
         for fused in (1, 0):
-            lib.iisan_set_sasrec_fused(fused)
+            _lib.dev_set("sasrec_fused", fused)
             params = [P["user_encoder.transformer_encoder." + k].cuda().contiguous() for k in order]
             grads = [torch.zeros_like(t) for t in params]
             x = torch.randn(B, S, E, device="cuda"); lm = torch.ones(B, S, device="cuda"); y = torch.empty_like(x); dy = torch.randn_like(x); dx = torch.empty_like(x)
@@ -32,4 +32,4 @@ for B in (128, 1024):
                 if it:
                     tf += ev[0].elapsed_time(ev[1]) / 5; tb += ev[1].elapsed_time(ev[2]) / 5
             print(f"B={B} p={p} fused={fused}: fwd {tf*1e3:.0f} us  bwd {tb*1e3:.0f} us  (ws {ws.numel()/1e6:.1f} MB)", flush=True)
-lib.iisan_set_sasrec_fused(1)
+_lib.dev_set("sasrec_fused", 1)

@@ -33,6 +33,6 @@ def run(versa, steps=10):
 for versa in (False, True):
     for rnd in range(2):
         for name, tm, sk in SETTINGS:
-            lib.iisan_set_gemm32_tuning(tm, sk)
+            (_lib.dev_set("gemm32_tm_thresh", tm), _lib.dev_set("gemm32_splitk_target", sk))
             print(f"{'versa ' if versa else 'cached'} round {rnd} {name:14s} {run(versa):.3f} ms/step", flush=True)
-lib.iisan_set_gemm32_tuning(0, 0)
+(_lib.dev_set("gemm32_tm_thresh", 0), _lib.dev_set("gemm32_splitk_target", 0))
