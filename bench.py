@@ -386,6 +386,7 @@ class Uncached:
         GEMM forced onto the 128x128 v1 kernels, which the GPU tests pin to the reference's golden taps: the CLS taps of all
         1,408 slots must agree within 16-bit accumulation-order noise (4e-4 per layer, far inside the 1.5e-3 tap budget) and
         the forward loss within the north-star 1e-3.  eval mode (no SASRec dropout), no parameter update."""
+        from iisan_amd import _lib
         b, loss, taps = self.batch, {}, {}
         enc = self.model.mm_encoder
         need = sorted(set([0] + list(enc.side_cv_adapter_num_list)))
@@ -398,13 +399,10 @@ class Uncached:
         try:
             with torch.no_grad():
                 for leg, v, fold in (("auto", 0, 2), ("img", 0, 0), ("v1", 1, 2)):
-                    _lib.dev_set("gemm16_variant", v)
-                    _lib.dev_set("ln_fold", fold)
-                    loss[leg] = float(self.model(self.ids, b.images, b.text, b.log_mask, None).item())
-                    taps[leg] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
+                    with _lib.dev(gemm16_variant=v, ln_fold=fold):
+                        loss[leg] = float(self.model(self.ids, b.images, b.text, b.log_mask, None).item())
+                        taps[leg] = (enc.cv_encoder.forward_taps(b.images, need), enc.bert_encoder.forward_taps(b.text, need))
         finally:
-            _lib.dev_set("gemm16_variant", 0)
-            _lib.dev_set("ln_fold", 2)
             self.set_full_blocks(False)
             self.model.train()
 

@@ -1001,8 +1001,8 @@ def test_default_dispatch_at_bs128_against_the_oracle_directly():
             r = enc_rows[i:i + 32]
             oc[r] = O.vit_cls_taps(b.images[r], vw, weights.VIT_BASE)
             ot[r] = O.bert_cls_taps(b.text[r], bw, weights.BERT_BASE)
-        oc[pad] = oc[pad[0]]
-        ot[pad] = ot[pad[0]]
+        oc[pad] = oc[pad[0]].clone()
+        ot[pad] = ot[pad[0]].clone()
         layers = O.side_layer_list(args.side_adapter_vit_list, False)
         ref, aux = O.model_loss_from_taps(b.ids, oc, ot, b.log_mask, b.pop_prob, P, layers)
     assert _lib.dev_state() == "", "this test is about the library's default routes"
