@@ -50,7 +50,10 @@ template <> struct Mfma16k16<BF16> {
 // no register prefetch, 136 VGPRs and 54.6 KB of LDS so that THREE workgroups share a CU: one loads and stages while two compute.
 // Measured 4 % SLOWER (415-421 against 398-411 us per ViT layer): a third wave per SIMD does not make up for the load phase a
 // workgroup now waits out.
-template <typename T, int NT16, bool PF>
+// MASKALL (round 5): true = the per-key limit is applied to every key tile (key_bias present, or a sequence that leaves more than the last
+// tile padded); false = compile-time knowledge that only the LAST tile can hold pad slots (no key_bias and S > 16 (NT16 - 1): ViT) — the
+// run-time test per tile made every tile its own basic block (~100 branches in the unrolled block loop).
+template <typename T, int NT16, bool PF, bool MASKALL>
 __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const typename T::elem* __restrict__ qkv,
                                                              const float* __restrict__ key_bias,
                                                              typename T::elem* __restrict__ ctx, int S, int heads, int hpw,
@@ -198,21 +201,29 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
             // masks afterwards, only on the tiles that can hold masked / padded keys (wave-uniform conditions)
 #pragma unroll
             for (int t = 0; t < NT16; ++t) {
-                if (key_bias != nullptr || t * 16 + 16 > S) {
+                if (MASKALL || t == NT16 - 1) {
                     const f4 kb = *(const f4*)(sKB + t * 16 + g * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) asm("v_min_f32 %0, %1, %2" : "=v"(sc[t][r]) : "v"(sc[t][r]), "v"(kb[r]));   // +inf keeps, MASK_RAW replaces (every real score is above it), -inf removes a pad slot:
-                                                                                       // one v_min per score (the nested select compiled to ~16 instructions and a branch each; fminf() adds two canonicalising v_max)
+                    // +inf keeps, MASK_RAW replaces (every real score is above it), -inf removes a pad slot: min(score, limit) as ONE
+                    // instruction the compiler can see — med3(score, limit, -inf).  (fminf() adds two canonicalising v_max; rounds 2-4 used an
+                    // inline-asm v_min_f32 here, which was only safe because a branch stood between it and the MFMAs: the hazard recognizer
+                    // does not look inside inline asm, and with the per-tile branches gone (round 5) the v_min read its MFMA result before
+                    // the matrix pipe had written it — 12 of 18 attention cases wrong.)
+                    for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_fmed3f(sc[t][r], kb[r], -INFINITY);
                 }
             }
-            float mx = -INFINITY;
+            // (round 5: two independent max chains and four independent sum chains instead of one 26-deep v_max3 chain and one 52-deep
+            //  v_add chain — the dependent-issue latency of those chains was exposed time, not arithmetic)
+            float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < NT16; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+            for (int t = 0; t < NT16; ++t) {
+                if (t & 1) mx1 = fmaxf(fmaxf(mx1, sc[t][0]), fmaxf(sc[t][1], fmaxf(sc[t][2], sc[t][3])));
+                else mx0 = fmaxf(fmaxf(mx0, sc[t][0]), fmaxf(sc[t][1], fmaxf(sc[t][2], sc[t][3])));
+            }
+            float mx = fmaxf(mx0, mx1);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
+            f4 sum4 = {0.f, 0.f, 0.f, 0.f};
             const float mxs = -(mx * c2);
 #pragma unroll
             for (int t = 0; t < NT16; ++t)
@@ -223,8 +234,9 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
                                                                   // is exactly 0 on all-masked rows because MASK_RAW is a power of two
                     const float p = __builtin_amdgcn_exp2f(a);          // (a run-time debug select here cost one v_cndmask per score)
                     sc[t][r] = p;
-                    sum += p;
+                    sum4[r] += p;
                 }
+            float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
@@ -438,8 +450,11 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     dim3 grid((unsigned)(items * (heads / hpw))), block(256);
     // (round 4 measured a three-workgroups-per-CU instantiation without register prefetch, PF = false: 415-421 us against 398-411 us per
     //  ViT layer for this one; it is no longer instantiated — round 5 route retirement)
-#define IISAN_ATTN_CASE(NT) \
-    hipLaunchKernelGGL((attention16_kernel<T, NT, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
+#define IISAN_ATTN_CASE(NT)                                                                                                       \
+    if (key_bias == nullptr && S > 16 * (NT - 1))                                                                                 \
+        hipLaunchKernelGGL((attention16_kernel<T, NT, true, false>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31); \
+    else                                                                                                                          \
+        hipLaunchKernelGGL((attention16_kernel<T, NT, true, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
     if (S <= 32) { IISAN_ATTN_CASE(2); }
     else if (S <= 64) { IISAN_ATTN_CASE(4); }
     else if (S <= 128) { IISAN_ATTN_CASE(8); }

@@ -368,7 +368,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     V8 xo[4][2];
     auto stream_load = [&](int tm, int tn, int half) {
         if constexpr (EPI == EPI_STREAM16) {
-            if (p.debug & 128) return;          // ablation: no stream loads (the sums are garbage)
+            if (p.debug & 128) {                // ablation: no stream loads (the sums are garbage).  The registers are DEFINED on this path
+                                                // too: left untouched, their previous contents stay live from one stream_load to the next
+                                                // epilogue — across the middle K-steps — and the production kernel spilled 12 of them per
+                                                // tile (3 scratch stores + 4 reloads, each reload behind an `s_waitcnt vmcnt(0)`; round 5)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) asm volatile("" : "=v"(xo[b][0]), "=v"(xo[b][1]));
+                return;
+            }
             int l2 = lane;
             asm volatile("" : "+v"(l2));
             const uint32_t lane_off = (uint32_t)((l2 & 31) * p.ldo * 2 + (l2 >> 5) * 32);
@@ -577,6 +584,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         if (p.debug & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
                             __builtin_nontemporal_store(o0, (V8*)op);
                             __builtin_nontemporal_store(o1, (V8*)(op + 16));
+                        } else if (p.debug & 512) {  // experiment (round 5): write-through stores that DROP the line from the XCD's L2 (sc1) ...
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(op), "v"(o0), "v"(o1) : "memory");
+                        } else if (p.debug & 1024) { // ... or system-scope write-through (sc0 sc1)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" :: "v"(op), "v"(o0), "v"(o1) : "memory");
                         } else {
                             *(V8*)op = o0;
                             *(V8*)(op + 16) = o1;

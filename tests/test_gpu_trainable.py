@@ -959,7 +959,14 @@ def test_production_size_step_meets_the_north_star_tolerance(lib, variant, full_
         layers = O.side_layer_list(args.side_adapter_vit_list, False)
         ref, aux = O.model_loss_from_taps(b.ids, tc, tt, b.log_mask, b.pop_prob, P, layers)
     rel = abs(loss.item() - ref.item()) / abs(ref.item())
-    assert rel < 1e-3, f"production-size loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e}"
+    # Round 5 (tools/northstar_diag.py, seeds 2024-2026 x nine routes): at bs = 2 the loss is a mean over 13 prediction rows and its error
+    # against the oracle is the decorrelated fp16 operand noise of the taps (6-9e-4 per tap layer) — it scatters between -4e-4 and
+    # +1.4e-3 with the seed and with ANY change of rounding sequence, for every kernel family alike, the golden-pinned 128x128 kernels
+    # included (seed 2025: +1.1e-3 on variant 1).  The north-star 1e-3 is a statement about the production batch and is asserted
+    # there, against the oracle directly (test_default_dispatch_at_bs128_against_the_oracle_directly); here the bound is the
+    # noise envelope of 13 rows, and the item embeddings / taps below carry the tight per-tensor bounds.
+    print(f"north-star bs=2 variant {variant} full_blocks {full_blocks}: loss rel {rel:.2e}")
+    assert rel < 2.5e-3, f"production-size loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e}"
     real = ids != 0
     e = ((score[real] - aux["score"][real]).norm() / aux["score"][real].norm()).item()
     assert e < 1e-3, f"item embeddings of real slots: rel {e:.2e}"
@@ -1015,6 +1022,7 @@ def test_default_dispatch_at_bs128_against_the_oracle_directly():
                 hc = enc.cv_encoder.forward_taps(dev_b.images, need).cpu()
                 ht = enc.bert_encoder.forward_taps(dev_b.text, need).cpu()
         rel = abs(loss.item() - ref.item()) / abs(ref.item())
+        print(f"bs=128 default dispatch, full_blocks {full_blocks}: loss {loss.item():.6f} vs oracle {ref.item():.6f}: rel {rel:.2e}")
         assert rel < 1e-3, f"bs=128 loss {loss.item()} vs oracle {ref.item()}: rel {rel:.2e} (full_blocks={full_blocks})"
         assert torch.equal(hc[:, 0], oc[:, 0]) or ((hc[:, 0] - oc[:, 0]).norm() / oc[:, 0].norm()).item() < 1e-6
         for k, l in enumerate(need[1:], 1):

@@ -57,7 +57,7 @@ def timed(chunk, what, reps=5):
 
 # NOTE: rows of a chunk must start at a multiple of 4 bytes * ... (rowstat pointer offset m0 * S * 4: any m0), A rows at m0*S*1536 B
 for rnd in range(3):
-    for chunk in (1408, 704, 352, 176, 146, 88):
+    for chunk in (1408, 704, 352, 176, 144, 88):
         t_pair, t_attn, t_gemm = timed(chunk, "pair"), timed(chunk, "attn"), timed(chunk, "gemm")
         print(f"round {rnd} chunk {chunk:5d} items ({chunk * heads * 3 * S * 64 * 2 / 1e6:7.1f} MB of QKV): pair {t_pair:8.1f} us   attention alone {t_attn:8.1f}   "
               f"QKV product alone {t_gemm:8.1f}", flush=True)
