@@ -584,10 +584,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         if (p.debug & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
                             __builtin_nontemporal_store(o0, (V8*)op);
                             __builtin_nontemporal_store(o1, (V8*)(op + 16));
-                        } else if (p.debug & 512) {  // experiment (round 5): write-through stores that DROP the line from the XCD's L2 (sc1) ...
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(op), "v"(o0), "v"(o1) : "memory");
-                        } else if (p.debug & 1024) { // ... or system-scope write-through (sc0 sc1)
-                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" :: "v"(op), "v"(o0), "v"(o1) : "memory");
                         } else {
                             *(V8*)op = o0;
                             *(V8*)(op + 16) = o1;
