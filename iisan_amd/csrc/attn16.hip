@@ -57,10 +57,18 @@ template <typename T, int NT16, bool PF, bool MASKALL>
 __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const typename T::elem* __restrict__ qkv,
                                                              const float* __restrict__ key_bias,
                                                              typename T::elem* __restrict__ ctx, int S, int heads, int hpw,
-                                                             int dbg) {
+                                                             int dbg_arg) {
     typedef typename T::elem E;
     typedef typename T::v8 V8;
     typedef typename T::v4 V4;
+#ifndef ATTN_DEBUG_BITS
+    // the ablation bits of tools/attn_time.py (dev switch attn_debug: 1 = no V^T write, 8 = no store, 16 = no K write) are compiled in
+    // only with -DATTN_DEBUG_BITS; the product build folds the tests away
+    (void)dbg_arg;
+    constexpr int dbg = 0;
+#else
+    const int dbg = dbg_arg;
+#endif
     constexpr int SP = NT16 * 16;
     // V^T row stride (elements), see VT_LD below; (history: 264 = 132 dwords was chosen for a half-wave (16 d-rows x 2 key
     // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).

@@ -93,6 +93,15 @@ __device__ __forceinline__ int nperm32s(int q) { return (q & ~31) + 16 * ((q >> 
 template <typename T, int EPI, bool LNA>
 __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int tiles_m, int tiles_n, uint32_t qkv_magic) {
     typedef typename T::v8 V8;
+    // Ablation / experiment bits (Gemm16Args::debug, set through the dev switch gemm16_variant = 4 | bits << 8; tools/gemm_walk.py, gemm_stream.py):
+    // compiled in only with -DGEMM16_DEBUG_BITS (`make EXTRA=-DGEMM16_DEBUG_BITS`).  The product build folds every test away: each
+    // run-time bit test in the epilogue costs scalar registers the kernel does not have (round 5: SGPR spills 17 / 18 -> 11 / 16 in the
+    // LayerNorm-epilogue instantiations with two of them gone).
+#ifdef GEMM16_DEBUG_BITS
+    const int dbg_bits = p.debug;
+#else
+    constexpr int dbg_bits = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * S_STAGE_BYTES ring + up to 8192 floats of bias
     float* sBias = (float*)(smem + 2 * S_STAGE_BYTES);
     float* sStat = (float*)(smem + 2 * S_STAGE_BYTES + LNA_STAT_OFF);             // LNA: [2][256] row statistics (rstd)
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     V8 xo[4][2];
     auto stream_load = [&](int tm, int tn, int half) {
         if constexpr (EPI == EPI_STREAM16) {
-            if (p.debug & 128) {                // ablation: no stream loads (the sums are garbage).  The registers are DEFINED on this path
+            if (dbg_bits & 128) {                // ablation: no stream loads (the sums are garbage).  The registers are DEFINED on this path
                                                 // too: left untouched, their previous contents stay live from one stream_load to the next
                                                 // epilogue — across the middle K-steps — and the production kernel spilled 12 of them per
                                                 // tile (3 scratch stores + 4 reloads, each reload behind an `s_waitcnt vmcnt(0)`; round 5)
@@ -420,10 +429,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
         asm volatile("" : "+v"(l2));
         const int frow = l2 & 31, fh = l2 >> 5;
         const bool full = (int64_t)(tm + 1) * SBM <= p.M;
-        stores8 = full && !(p.debug & (1 | 32));        // (EPI_STREAM16: one more, the row statistics — S256_VMCNT_EPI)
+        stores8 = full && !(dbg_bits & (1 | 32));        // (EPI_STREAM16: one more, the row statistics — S256_VMCNT_EPI)
         const int row0 = tm * SBM + grp * 128;                 // first row of the group's half of the tile
         const int col0 = tn * SBN + wq * 64;                   // first column of the wave's slice
-        if (!(p.debug & 1)) {
+        if (!(dbg_bits & 1)) {
             auto run = [&](auto FULL_T) {                      // FULL (compile time): no row test
                 constexpr bool FULL = decltype(FULL_T)::value;
                 // byte offset of the lane's 32 bytes (16 columns) inside a 32 x 32 block at (mi, ni)
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                     const f2 a0 = sSum[0], a1 = sSum[64], a2 = sSum[128], a3 = sSum[192];       // blocks (mi, ni) = (0,0) (1,0) (0,1) (1,1)
                     const f2 st = (f2){both(a0[0] + a2[0], a1[0] + a3[0]), both(a0[1] + a2[1], a1[1] + a3[1])};
                     const int64_t slot = (int64_t)(col0 >> 6) * ((int64_t)tiles_m * SBM);
-                    if (!(p.debug & 256)) *(f2*)(p.rowpart + (slot + row0 + (2 * half + fh) * 32 + frow) * 2) = st;      // (ablation bit: no statistics store)
+                    if (!(dbg_bits & 256)) *(f2*)(p.rowpart + (slot + row0 + (2 * half + fh) * 32 + frow) * 2) = st;      // (ablation bit: no statistics store)
                     return;
                 }
 #pragma unroll
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         o1[e] = T::from_f32(g[4 + e / 2][0]); o1[e + 1] = T::from_f32(g[4 + e / 2][1]);
                     }
 #ifdef S256_TIMELINE
-                    if (p.debug & 32) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
+                    if (dbg_bits & 32) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }     // ablation: the arithmetic alone
 #endif
                     const int mrow = row0 + mi * 32;                       // (wave-uniform) first row of the block
                     char* op;
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
                     }
                     if (ok) {
-                        if (p.debug & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
+                        if (dbg_bits & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
                             __builtin_nontemporal_store(o0, (V8*)op);
                             __builtin_nontemporal_store(o1, (V8*)(op + 16));
                         } else {
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
 #ifdef S256_TIMELINE
     unsigned* sStamp = (unsigned*)(smem + 2 * S_STAGE_BYTES + STG_BIAS_BYTES - 4096) + grp * 512;     // (timeline builds: the last 4 KiB of the bias area, N <= 3072)
     int dbg_n = 0;
-    const bool dbg_on = (p.debug & 16) && blockIdx.x == 0 && wq == 0;
+    const bool dbg_on = (dbg_bits & 16) && blockIdx.x == 0 && wq == 0;
     auto stamp = [&]() {
         if (dbg_on && dbg_n < 512) {
             if (lane == 0) sStamp[dbg_n] = (unsigned)(__builtin_readcyclecounter() - dbg_t0);
@@ -626,12 +635,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     auto stamp2 = [] {};
     (void)stamp2;
 #endif
-    if (p.debug & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
+    if (dbg_bits & 4) {                         // experiment: spread the CUs' tile phases over ~one tile time
         const int units = (int)(((unsigned)pid * 40503u) >> 5) & 63;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
-    if (p.debug & 8) {                         // experiment: one phase per XCD (L2 sharing inside an XCD is kept), spread over
-        const int units = (int)(blockIdx.x & 7) * nk * ((p.debug >> 8) & 15) / 12;     // (debug>>8)&15 kilo-cycles per XCD at K=768
+    if (dbg_bits & 8) {                         // experiment: one phase per XCD (L2 sharing inside an XCD is kept), spread over
+        const int units = (int)(blockIdx.x & 7) * nk * ((dbg_bits >> 8) & 15) / 12;     // (debug>>8)&15 kilo-cycles per XCD at K=768
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
     for (int i = tid; i < p.N; i += 512) sBias[i] = p.bias ? p.bias[i] : 0.f;
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
     // The plan is unconditional, so the last MFMA slots issued LDS-DMA loads nobody reads: they must have landed before
     // this workgroup's LDS can be handed to another workgroup.
     S256_VMCNT(0);
-    if ((p.debug & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
+    if ((dbg_bits & 16) && tid == 0) {          // development aid: cycles and K-steps of this workgroup into out[]
         ((long long*)p.out)[2 * blockIdx.x] = __builtin_readcyclecounter() - dbg_t0;
         ((long long*)p.out)[2 * blockIdx.x + 1] = nsteps;
     }
