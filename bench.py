@@ -56,9 +56,10 @@ def parse(argv=None):
                     help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
                          "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
     ap.add_argument("--overlap-towers", dest="overlap_towers", action="store_true", default=False,
-                    help="opt-in (`mm_encoder.overlap_towers = True`): BERT tower on a second HIP stream beside the ViT tower — same "
-                         "kernels, same results, -1.6 %% step time.  Kernels of the two towers then share the CUs, so per-kernel durations "
-                         "(events and rocprofv3 alike) stop being a kernel measure; `roofline` times the main stream's launches only")
+                    help="opt-in (`mm_encoder.overlap_towers = True`): ViT tower on a high-priority HIP stream, BERT tower on a normal-priority one "
+                         "beside it — same kernels, same results, -0.3 .. -0.4 ms per step (profiles/r5_overlap.md).  Kernels of the two towers then "
+                         "share the CUs, so per-kernel durations (events and rocprofv3 alike) stop being a kernel measure; "
+                         "`roofline.dominant_kernel` times the image tower's launches only")
     ap.add_argument("--no-overlap-towers", dest="overlap_towers", action="store_false", help="(the default) both towers on one stream")
     ap.add_argument("--cached", choices=["fp32", "fp16", "bf16"], default=None,
                     help="secondary workload (BASELINE config 3, never the headline): Code_Cached IISAN fed from a "
@@ -451,17 +452,19 @@ class Uncached:
             enc.overlap_towers = overlap
         clock = Clock(self.dev, world)
         # overlapped towers: only the launches on the main stream (the ViT tower) are a kernel measure (csrc/timing.cpp)
-        lib.iisan_timing_only_stream(torch.cuda.current_stream().cuda_stream, 1 if enc.overlap_towers else 0)
+        lib.iisan_timing_only_stream(enc.tower_streams()[0].cuda_stream if enc.overlap_towers else None, 1 if enc.overlap_towers else 0)
         try:
-            if world > 1:                       # warm-up outside the all-reduce timing, then HIP events around every collective
-                for _ in range(warmup):
-                    self.step()
+            # Two passes of the same K steps (round 5; the Cached line has always done this): `value` / `ms_per_step` come from a pass
+            # with NO instrumentation inside the timed region; the per-launch HIP events of `roofline.dominant_kernel` (194 event
+            # records per step on the launching stream) and the all-reduce events of a multi-rank run ride on a second pass —
+            # same-box A/B, three interleaved rounds of 20 steps: the events cost +0.34 ms per step (tools/overlap_ab.py,
+            # profiles/r5_overlap.md).
+            elapsed, loss = clock.run(self.step, warmup, steps)
+            if world > 1:
                 self.tr.time_allreduce = True
                 self.tr.allreduce_ms()
-                elapsed, loss = clock.run(self.step, 0, steps, lib, timed=self.rank == 0)
-                self.tr.time_allreduce = False
-            else:
-                elapsed, loss = clock.run(self.step, warmup, steps, lib, timed=self.rank == 0)
+            elapsed_ev, _ = clock.run(self.step, 0, steps, lib, timed=self.rank == 0)
+            self.tr.time_allreduce = False
         finally:
             self.set_full_blocks(False)
             lib.iisan_timing_only_stream(None, 0)
@@ -486,8 +489,8 @@ class Uncached:
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        **({"distributed": dinfo} if dinfo else {}),
-                       "towers": ("text tower on a second HIP stream beside the image tower (same kernels, same results); `roofline.dominant_kernel` times the "
-                                  "gemm16 launches of the main stream = the ViT tower (87 % of the encoder GEMM FLOPs)") if overlapped
+                       "towers": ("image tower on a high-priority HIP stream, text tower on a normal-priority one beside it (same kernels, same results); "
+                                  "`roofline.dominant_kernel` times the gemm16 launches of the image tower's stream (87 % of the encoder GEMM FLOPs)") if overlapped
                                  else "both towers on one stream; `roofline.dominant_kernel` times every gemm16 launch",
                        "encoder_blocks": "all tokens in every block" if full_blocks else
                                          "WORK PRUNING: last block computes K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
@@ -498,7 +501,7 @@ class Uncached:
             "roofline": {"bound": "mfma", "achieved": value / world * FLOP_PER_SLOT / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": value / world * FLOP_PER_SLOT / MFMA_PEAK,
                          "definition": "whole step (SURVEY 8d): items/s per GPU x 40.28e9 FLOP per item slot / 2.5e15",
-                         "executed_gemm_flops_frac": fl.value / elapsed / MFMA_PEAK,
+                         "executed_gemm_flops_frac": fl.value / elapsed_ev / MFMA_PEAK,
                          # bytes per launch of the dominant kernel at the L2's memory side: NOT measured by this run (PMC counters
                          # cannot be read from inside it) but read from the committed summary of two rocprofv3 --pmc passes of this
                          # command with this configuration; null for any other configuration
@@ -512,6 +515,7 @@ class Uncached:
                              "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                              "flop_per_launch": fl.value / max(n_launch, 1),
                              "ms_per_step": ms.value / max(steps, 1),
+                             "measured_in": f"a second pass of the same {steps} steps with HIP events around every launch ({elapsed_ev / steps * 1e3:.3f} ms per step with them)",
                              "traffic": traffic, "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1)}},
         }
 
@@ -618,8 +622,8 @@ def secondary_lines(a, unc, lib, dev, rank, world):
         "on the CLS rows only (taps identical)", lambda: unc.line(k, w, "fp16", False, headline=False))
     add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", True, headline=False))
     unc.set_dtype(a.dtype)
-    add("uncached, text tower on a second HIP stream beside the image tower (opt-in `mm_encoder.overlap_towers`; same kernels, same "
-        "results; the two towers' kernels share the CUs, so `roofline` — the main stream's gemm16 launches — is not a clean kernel measure here)",
+    add("uncached, image tower on a high-priority HIP stream with the text tower on a normal-priority one beside it (opt-in `mm_encoder.overlap_towers`; same "
+        "kernels, same results; the two towers' kernels share the CUs, so `roofline.dominant_kernel` — the image tower's gemm16 launches — is not a clean kernel measure here)",
         lambda: unc.line(k, w, a.dtype, True, headline=False, overlap=True))
     unc.set_dtype(a.dtype)
     c3 = argparse.Namespace(**{**vars(a), "cached": "fp32", "versa": False, "bs": 1024})

@@ -116,25 +116,35 @@ class IISANAdaptedMModel(_SideNetBase):
             taps_text = self.bert_encoder.forward_taps(sample_items_text.index_select(0, first), need).index_select(0, inverse)
         else:
             if getattr(self, "overlap_towers", False) and sample_items_images.is_cuda:
-                # opt-in: the text tower on a second HIP stream, so its kernels fill the tails of the image tower's persistent
-                # GEMMs (same kernels, same results; -1.6 % step time: 66.7 -> 65.6 ms at bs = 128, round 4).  Not the default:
-                # the towers' kernels then share the CUs and every per-kernel duration (HIP events, rocprofv3) is inflated by
-                # the sharing — a ViT GEMM's trace duration grows from 0.39 to 0.75 ms — so the step stops being accountable
-                # kernel by kernel (profiles/r4_overlap_by_stream.md)
+                # opt-in: the two towers on two HIP streams of their own — the image tower on a HIGH-priority stream, the text tower on a
+                # normal one — so that the text tower's kernels only fill what the image tower's persistent GEMMs leave free (their
+                # partial last rounds).  Same kernels, same results.  Round 5 (profiles/r5_overlap.md, same box, three interleaved rounds of
+                # 20 steps): -0.33 / -0.41 ms per step, every round; with BOTH towers at normal priority the step is bimodal (-0.5 ms or
+                # +1.2 .. +4.3 ms: a text-tower GEMM that wins a CU keeps it for its whole static tile list and the image tower's
+                # kernel waits for it).  Not the default: the gain is below the 0.8 ms the round-4 review asked for, and per-kernel
+                # durations (HIP events, rocprofv3) are inflated by the sharing (profiles/r4_overlap_by_stream.md).
                 cur = torch.cuda.current_stream()
-                if getattr(self, "_side_stream", None) is None:
-                    self._side_stream = torch.cuda.Stream()
-                side = self._side_stream
+                hi, side = self.tower_streams()
                 side.wait_stream(cur)
+                hi.wait_stream(cur)
                 with torch.cuda.stream(side):
                     taps_text = self.bert_encoder.forward_taps(sample_items_text, need)
-                taps_cv = self.cv_encoder.forward_taps(sample_items_images, need)
+                with torch.cuda.stream(hi):
+                    taps_cv = self.cv_encoder.forward_taps(sample_items_images, need)
                 cur.wait_stream(side)
+                cur.wait_stream(hi)
                 taps_text.record_stream(cur)
+                taps_cv.record_stream(cur)
             else:
                 taps_cv = self.cv_encoder.forward_taps(sample_items_images, need)
                 taps_text = self.bert_encoder.forward_taps(sample_items_text, need)
         return self._side(taps_cv, taps_text, [need.index(l) for l in layers], need.index(0) if self.remove_first else 0)
+
+    def tower_streams(self):
+        """(image-tower stream: high priority, text-tower stream: normal priority) of the opt-in `overlap_towers` mode, created on first use."""
+        if getattr(self, "_tower_streams", None) is None:
+            self._tower_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream())
+        return self._tower_streams
 
     def forward(self, sample_items_images, sample_items_text):
         return self.forward_item3(sample_items_images, sample_items_text)[1]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """settle the overlapped-towers question with evidence.  One process, one box: the headline step (both towers on one
-stream) against the text tower on a second HIP stream of normal / low priority — 20 timed steps per leg, three interleaved rounds,
+stream) against the text tower on a second HIP stream (both at normal priority / the image tower at high priority) — 20 timed steps per leg, three interleaved rounds,
 no per-launch events inside the timed regions.  Prints a markdown table (copy to profiles/r5_overlap.md).
 
     python tools/overlap_ab.py [rounds=3] [steps=20]
@@ -27,27 +27,26 @@ unc.set_full_blocks(True)
 enc = unc.model.mm_encoder
 lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
 print(f"stream priority range (least, greatest): {lo}, {hi}", flush=True)
-LEGS = [("one stream (headline)", False, None), ("text tower on a 2nd stream, normal priority", True, 0),
-        ("text tower on a 2nd stream, LOW priority", True, 1), ("text tower on a 2nd stream, ViT stream HIGH priority", True, "main_high")]
+LEGS = [("one stream (headline)", False, None), ("one stream + HIP events around every gemm16 launch (bench.py's instrumented pass)", False, "events"),
+        ("towers on two streams, BOTH normal priority (the round-4 opt-in)", True, "both_normal"),
+        ("image tower on a HIGH-priority stream, text tower on a normal one (the opt-in `overlap_towers` as shipped)", True, "product")]
 res = {name: [] for name, _, _ in LEGS}
 loss = {}
 clock = bench.Clock(dev, 1)
-high = torch.cuda.Stream(priority=-1)
 for rnd in range(rounds):
-    for name, ov, prio in LEGS:
+    for name, ov, kind in LEGS:
         enc.overlap_towers = ov
-        if ov:
-            enc._side_stream = torch.cuda.Stream(priority=prio if isinstance(prio, int) else 0)
-        if prio == "main_high":
-            high.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(high):
-                el, ls = clock.run(unc.step, 3, steps)
-            torch.cuda.current_stream().wait_stream(high)
+        enc._tower_streams = (torch.cuda.Stream(), torch.cuda.Stream()) if kind == "both_normal" else None
+        if kind == "events":
+            import ctypes as C
+            el, ls = clock.run(unc.step, 3, steps, lib, timed=True)
+            lib.iisan_timing_collect(C.byref(C.c_double(0)), C.byref(C.c_double(0)))
         else:
             el, ls = clock.run(unc.step, 3, steps)
         res[name].append(el / steps * 1e3)
         loss[name] = float(ls.item())
         print(f"round {rnd} {name}: {el / steps * 1e3:.3f} ms/step (loss {loss[name]:.6f})", flush=True)
+enc._tower_streams = None
 enc.overlap_towers = False
 base = statistics.median(res[LEGS[0][0]])
 print("\n| leg | ms/step per round | median | vs headline | items/s | whole-step fraction (x 40.28 GF / 2.5 PF) |\n|---|---|---|---|---|---|")
