@@ -21,8 +21,12 @@
 #define ATTN_KBATCH 4
 #endif
 
-static int g_attn_dbg = 0;
+#ifdef ATTN_DEBUG_BITS
+static int g_attn_dbg = 0;            // ablation builds only (tools/attn_time.py): bits 0..4 = kernel ablations, bits 8..11 = heads per workgroup
 IISAN_DEV_KNOB(attn_debug, g_attn_dbg);
+#else
+static constexpr int g_attn_dbg = 0;
+#endif
 
 namespace {
 
@@ -46,7 +50,7 @@ template <> struct Mfma16k16<BF16> {
 };
 
 // PF (prefetch): true (the product) — the next head's Q / K / V registers fill from HBM during this head's compute (92 registers held
-// across it: 227 VGPRs, two waves per SIMD, two workgroups per CU); false (round 4 experiment, kept behind iisan_set_attn_debug(32)) =
+// across it: 227 VGPRs, two waves per SIMD, two workgroups per CU); false (round 4 experiment, no longer instantiated) =
 // no register prefetch, 136 VGPRs and 54.6 KB of LDS so that THREE workgroups share a CU: one loads and stages while two compute.
 // Measured 4 % SLOWER (415-421 against 398-411 us per ViT layer): a third wave per SIMD does not make up for the load phase a
 // workgroup now waits out.
@@ -451,10 +455,12 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     // heads per workgroup: 2 (one head computing, the next one's Q/K/V in flight).  On the spill-free kernel 1 / 2 / 4 / 6
     // heads measured 420 / 421 / 428 / 437 us per ViT layer in isolation and 68.55 / 68.58 / 68.78 ms per step
     int hpw = heads % 2 == 0 ? 2 : 1;
-    {   // development knob (tools/attn_pf_ab.py): bits 8..11 of iisan_set_attn_debug = heads per workgroup, when it divides the head count
+#ifdef ATTN_DEBUG_BITS
+    {   // ablation builds (tools/attn_pf_ab.py): bits 8..11 of dev switch attn_debug = heads per workgroup, when it divides the head count
         const int want = (g_attn_dbg >> 8) & 15;
         if (want > 0 && heads % want == 0) hpw = want;
     }
+#endif
     dim3 grid((unsigned)(items * (heads / hpw))), block(256);
     // (round 4 measured a three-workgroups-per-CU instantiation without register prefetch, PF = false: 415-421 us against 398-411 us per
     //  ViT layer for this one; it is no longer instantiated — round 5 route retirement)

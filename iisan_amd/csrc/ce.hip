@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void ce_colpass_kernel(const float* __restrict
 // 1 (default): one fused FWD + DPREC row pass (online softmax) and the cooperative column pass; 2: separate FWD and DPREC
 // row passes (round-2a form); 0: the generic kernel everywhere (test knob)
 int g_ce_fast = 1;
-int g_ce_dbg = 0;
+constexpr int g_ce_dbg = 0;      // (the ablation bits of the fused row pass: compile-time zero since round 5)
 bool rowpass_ok(int64_t bs, int S) { return g_ce_fast && S >= 5 && S + 1 <= MAXS1 && bs * (int64_t)(S + 1) < (1ll << 31); }
 
 int check(int64_t bs, int S, int Ein) {
@@ -839,7 +839,6 @@ static uint64_t ce_token(int64_t bs, int32_t S, int fused) {
     return 0xCE00000000000000ull | ((uint64_t)(bs & 0xFFFFFFFFll) << 16) | ((uint64_t)(S & 0xFF) << 8) | (uint64_t)(fused ? 2 : 1);
 }
 IISAN_DEV_KNOB(ce_fast, g_ce_fast);
-IISAN_DEV_KNOB(ce_debug, g_ce_dbg);        // ablation bits of the fused row pass (timing only)
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,
@@ -900,7 +899,7 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
         iisan_set_error("inbatch_ce_bwd: fwd_token %llx is not what inbatch_ce_fwd returns for bs = %lld, S = %d", (unsigned long long)fwd_token, (long long)bs, S);
         return IISAN_EBADSHAPE;
     }
-    if (fused)        // d_prec for d_loss = 1 is in the workspace (whatever iisan_set_ce_fast says by now)
+    if (fused)        // d_prec for d_loss = 1 is in the workspace (whatever the dev switch ce_fast says by now)
         hipLaunchKernelGGL(ce_scale_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(T * E / 4, 256), 1024)), dim3(256), 0, s, b.dprec, d_loss, d_prec, T * E / 4);
     else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_DPREC, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, d_loss, d_prec);

@@ -257,13 +257,7 @@ static int g_variant = 0;
 static int g_auto_staggered = 1;
 // auto policy: which staggered kernel takes the production shapes — 1 = gemm16_h256.hip (half-slot tile boundary: same-box
 // A/B of tools/gemm_var.py over three boxes: QKV +1..4 %, O +1 %, FC1 +-0, FC2 +3..4 %; bit-identical results), 0 = gemm16_s256.hip.
-static int g_auto_h256 = 1;
-IISAN_DEV_KNOB(gemm16_h256, g_auto_h256);
-// 1: the staggered kernel starts its workgroups up to ~one tile time apart on the short-K products with store-heavy
-// epilogues (QKV scatter, FC1 GELU), so the CUs' store bursts stop coinciding (tools/gemm_time.py: QKV 963 -> 988, FC1 900 ->
-// 913 TF; O -2 %, FC2 -7 %: not applied there).  Knob for the A/B (tools/desync_ab.py).
-static int g_desync = 0;
-IISAN_DEV_KNOB(gemm16_desync, g_desync);
+// (round 5: the switch that sent the production shapes back to gemm16_s256.hip is retired; variant 3 still forces that kernel for the race screen)
 IISAN_DEV_KNOB(gemm16_variant, g_variant);
 // tile walk of gemm16_h256 (bench knob): c = -1 auto policy, 0 = row-major tile list, > 0 = panels of c column tiles walked down
 // sub-slabs of h row tiles (h <= 0: the XCD's whole slab)
@@ -286,7 +280,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const int var = g_variant & 0xff;
     const bool big = var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
-    if (big && (var == 4 || (var == 0 && g_auto_staggered && g_auto_h256)) && gemm16_h256_applicable(mode, a)) {
+    if (big && (var == 4 || (var == 0 && g_auto_staggered)) && gemm16_h256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
         // auto policy (tools/gemm_walk.py, three boxes, interleaved rounds: QKV 1,010 -> 1,045, FC1 972 -> 990 TFLOP/s; the L2 read
@@ -307,7 +301,6 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
-        if (g_desync && (mode == EPI_QKVH16 || mode == EPI_GELU16) && a.K <= 1024) b.debug |= 4;
         rc = launch_gemm16_s256(dtype16, mode, b, s);
     }
     // everything else — small shapes, the fp32 / residual epilogues (round 4 retired the lock-step 256x256 kernel gemm16_p256.hip: its
@@ -325,7 +318,7 @@ bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a) {
     Gemm16Args b = a;
     static const float dummy = 0.f;
     if (!b.rowstat) b.rowstat = &dummy;
-    return dtype16 == IISAN_F16 && big && (var == 4 || (g_auto_staggered && g_auto_h256)) && a.N % BN == 0 && a.K % BK == 0 &&
+    return dtype16 == IISAN_F16 && big && (var == 4 || g_auto_staggered) && a.N % BN == 0 && a.K % BK == 0 &&
            gemm16_h256_applicable(mode, b);
 }
 
@@ -333,7 +326,7 @@ bool gemm16_takes_rowstat(int dtype16, int mode, const Gemm16Args& a) {
 bool gemm16_runs_h256(int dtype16, int mode, const Gemm16Args& a) {
     const int var = g_variant & 0xff;
     const bool big = var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
-    return (mode != EPI_STREAM16 || dtype16 == IISAN_F16) && big && (var == 4 || (g_auto_staggered && g_auto_h256)) && a.N % BN == 0 &&
+    return (mode != EPI_STREAM16 || dtype16 == IISAN_F16) && big && (var == 4 || g_auto_staggered) && a.N % BN == 0 &&
            a.K % BK == 0 && gemm16_h256_applicable(mode, a);
 }
 

@@ -857,14 +857,11 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int 
 // each other's scratch
 thread_local float* g_scratch = nullptr;
 thread_local size_t g_scratch_floats = 0;
-int g_accum_via_scratch = 1;       // 0: weight-gradient split-K sums by atomics (test / bench knob, iisan_set_gemm32_tuning)
+constexpr int g_accum_via_scratch = 1;       // (weight-gradient split-K sums go through the executor's scratch; the atomics route's switch was retired in round 5)
 
-// launch-shape heuristics (bench / tuning knob iisan_set_gemm32_tuning): workgroups wanted before the row tile shrinks /
+// launch-shape heuristics (constants since round 5; tools/step_ab.py measured them): workgroups wanted before the row tile shrinks /
 // before split-K stops adding slices
-static int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
-IISAN_DEV_KNOB(gemm32_accum_scratch, g_accum_via_scratch);
-IISAN_DEV_KNOB_FN(gemm32_tm_thresh, g_tm_thresh, g_tm_thresh = v > 0 ? (int)v : 512);
-IISAN_DEV_KNOB_FN(gemm32_splitk_target, g_splitk_target, g_splitk_target = v > 0 ? (int)v : 1024);
+static constexpr int g_tm_thresh = 512, g_splitk_target = 1024;   // tools/step_ab.py (MI355X): row tiles shrink below 512 workgroups: Versa 9.88 -> 9.55 ms, Cached unchanged; split-K target 512 or 2048: no gain
 
 template <int FLAGS>
 int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bool deep, hipStream_t s) {

@@ -49,8 +49,6 @@ struct SanbArgs {
     SanbTower t[3];
     int64_t M;
     int32_t gelu;
-    int32_t debug;      // ablation bits (iisan_set_sanb_debug): 1 = skip the narrow product, 2 = skip the wide product
-    int32_t stagger;    // start delay of tower y's workgroups: y * stagger * ~4 us (see launch_sanb)
 };
 
 // Workgroups are persistent (grid.x = one per CU and tower, each walks its tiles).  Ablation at the Cached batch size
@@ -58,10 +56,6 @@ struct SanbArgs {
 // the phases of the three co-resident workgroups do NOT overlap: they start together and stay in lock-step.  A one-off start
 // offset per tower (this function) was tried and is off by default: 2 / 4 / 8 units of ~4 us made the Cached step 6.55 /
 // 6.75 / 6.80 ms against 6.51 — at 150 us per launch the delay costs more than the overlap returns.
-__device__ __forceinline__ void stagger(int units) {
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
-}
-
 // LDS: tile [16][D+4] | [16][68]
 __host__ __device__ constexpr int lds_floats(int D) { return R * (D + 4) + R * UST; }
 
@@ -159,7 +153,6 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
-    stagger(args.stagger * (int)blockIdx.y);
     const int64_t ntiles = (args.M + R - 1) / R;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t m0 = tile * R;
@@ -199,7 +192,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
 
     // ---- 2. U = F · Wd^T + bd ; A = act(U) : one 16 x 16 fragment per wave -----------------------------------------
     {
-        const f4 u4 = (args.debug & 1) ? (f4){0.f, 0.f, 0.f, 0.f} : narrow_product<D>(Fs, t.Wd, wave, lane);
+        const f4 u4 = narrow_product<D>(Fs, t.Wd, wave, lane);
         const int col = wave * 16 + (lane & 15);
         const float bd = t.bd[col];
 #pragma unroll
@@ -218,7 +211,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_fwd_kernel(SanbArgs args) {
     __syncthreads();
 
     // ---- 3. O = A · Wu^T + bu + F, in place in LDS -----------------------------------------------------------------
-    if (!(args.debug & 2)) wide_product<D>(Fs, As, t.Wu, t.bu, wave, lane);
+    wide_product<D>(Fs, As, t.Wu, t.bu, wave, lane);
     __syncthreads();
 
     // ---- 4. tile -> HBM, full rows -----------------------------------------------------------------------------------
@@ -246,7 +239,6 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool gated = t.gate != nullptr;
     const float g = gated ? gate_of(t.gate) : 1.0f;
-    stagger(args.stagger * (int)blockIdx.y);
     const int64_t ntiles = (args.M + R - 1) / R;
     float gate_part = 0.f;
     float dbu_acc[D / NT], dbd_acc = 0.f;
@@ -291,7 +283,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
 
     // ---- 2. dU = (dO · Wu) ⊙ act'(U) -> LDS and HBM ------------------------------------------------------------------
     {
-        const f4 da = (args.debug & 1) ? (f4){0.f, 0.f, 0.f, 0.f} : narrow_product<D>(Gs, t.Wd, wave, lane);
+        const f4 da = narrow_product<D>(Gs, t.Wd, wave, lane);
         const int col = wave * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -315,7 +307,7 @@ __global__ __launch_bounds__(NT, 3) void sanb_bwd_kernel(SanbArgs args) {
     }
 
     // ---- 3. dF = dO + dU · Wd, in place in LDS ---------------------------------------------------------------------------
-    if (!(args.debug & 2)) wide_product<D>(Gs, Ds, t.Wu, nullptr, wave, lane);
+    wide_product<D>(Gs, Ds, t.Wu, nullptr, wave, lane);
     __syncthreads();
 
     // ---- 4. gate gradient, dprev (and the dim-align gradients) with full-row accesses ---------------------------------------
@@ -404,16 +396,15 @@ static void fill(SanbTower& t, const SanbTowerDesc& d) {
     t.dO = d.dO; t.Upre = d.Upre; t.dU = d.dU; t.dprev = d.dprev; t.da = d.da; t.db = d.db; t.dgate = d.dgate; t.dbu = d.dbu; t.dbd = d.dbd;
 }
 
-static int g_sanb_debug = 0, g_sanb_stagger = 0, g_sanb_persist = 1;
-IISAN_DEV_KNOB(sanb_debug, g_sanb_debug);
-IISAN_DEV_KNOB(sanb_persistent, g_sanb_persist);
-IISAN_DEV_KNOB(sanb_stagger, g_sanb_stagger);
+// (round 5: the ablation bits, the start-stagger experiment and the non-persistent grid lost their switches: measured, documented in
+//  DESIGN 6c / 6d, never the product route)
+static constexpr int g_sanb_persist = 1;
 
 template <bool BWD>
 static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) {
     IISAN_CHECK_SHAPE(n >= 1 && n <= 3 && M > 0, "sanb: 1..3 towers per launch");
     SanbArgs a{};
-    a.M = M; a.gelu = gelu; a.debug = g_sanb_debug & 15; a.stagger = g_sanb_stagger;
+    a.M = M; a.gelu = gelu;
     const int D = towers[0].D;
     for (int i = 0; i < n; ++i) {
         IISAN_CHECK_SHAPE(towers[i].D == D && sanb_fused_ok(D, RD), "sanb: towers of one launch must share a supported width");

@@ -615,8 +615,7 @@ __global__ __launch_bounds__(256) void sasrec_reduce_kernel(const float* __restr
 
 // The fused path covers the production configuration; anything else stays on the per-operator launches of sasrec.hip.
 static int g_sasrec_fused = 1;
-static long long* g_sasrec_stamps = nullptr;
-IISAN_DEV_KNOB(sasrec_stamps, g_sasrec_stamps);      // device pointer of a cycle-stamp buffer (tools/sasrec_stamps.py), 0 = none
+static constexpr long long* g_sasrec_stamps = nullptr;      // (the stage-timeline switch of tools/sasrec_stamps.py was retired in round 5)
 IISAN_DEV_KNOB(sasrec_fused, g_sasrec_fused);
 bool sasrec_fused_shape_ok(const iisan_sasrec_cfg* cfg) {       // (the workspace is sized by this alone: the knob only picks kernels)
     return cfg->emb == FE && cfg->seq >= 1 && cfg->seq <= 16 && cfg->heads >= 1 && FE % cfg->heads == 0 &&

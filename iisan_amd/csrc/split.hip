@@ -238,7 +238,7 @@ static bool x3_shape_ok(const Gemm32Prob& p, int flags) {
 //   172 vs 265 (1.5x) and its dW 133 vs 241 (1.8x); [4373,768]x[768,768] (the distinct ids of a bs = 1024 batch) 61 vs 86
 //   (1.4x), its dW 74 vs 75; [2816,768]x[768,768] 54 vs 50-55 (even); [1408,768]x[768,768] 45 vs 30 us (0.7x: stays on
 //   the f32 cores).
-// ONE default for the product, the tests and the bench (iisan_set_x3(1) restores exactly this value): products of at least
+// ONE default for the product, the tests and the bench (dev switch x3 = 1 restores exactly this value): products of at least
 // 4 GFLOP take the split-operand route ([4373, 768]x[768, 768] 61 vs 86 us; [2816, 768]x[768, 768] even)
 constexpr double X3_DEFAULT_MIN_FLOPS = 4e9;
 static double g_x3_min_flops = X3_DEFAULT_MIN_FLOPS;
