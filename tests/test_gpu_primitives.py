@@ -311,7 +311,9 @@ def _attn_ref(qkv, key_bias, items, S, heads):
                                   (2, 64, 3, False), (2, 100, 2, True),
                                   # 14 key tiles (S = 209..224): ADVICE r4 — the V^T row stride of the 13-tile kernel (212) was applied to
                                   # this instantiation too: neighbouring head dims overlapped and the last row ran into the key limits
-                                  (2, 224, 2, False), (2, 209, 3, True), (1, 208, 2, True)])
+                                  (2, 224, 2, False), (2, 209, 3, True), (1, 208, 2, True),
+                                  # round 5: every tile count's MASKALL = false instantiation (no key_bias, only the last tile can hold pad slots)
+                                  (3, 20, 2, False), (2, 120, 2, False), (2, 128, 3, False), (2, 32, 2, False)])
 def test_attention16_vs_torch(lib, dt, case):
     items, S, heads, masked = case
     g = torch.Generator().manual_seed(S * 13 + heads)
