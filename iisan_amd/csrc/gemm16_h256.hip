@@ -589,6 +589,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         op = base + lane_off;
                         if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
                     }
+                    if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16) {
+                        if (dbg_bits & 512) {
+                            // experiment (round 5, timing only — the DATA lands in the wrong places): the same two stores per block, but each
+                            // instruction writes 8 complete 128-byte rows of the wave's 64-column slice (8 cache lines) instead of two 16-byte
+                            // pieces in each of 32 rows (32 lines).  What would line-complete stores be worth if the rearrangement were free?
+                            char* b0 = (char*)p.out + ((int64_t)(mrow + 16 * ni + (l2 >> 3)) * p.ldo + col0) * 2 + (l2 & 7) * 16;
+                            *(V8*)b0 = o0;
+                            *(V8*)(b0 + (int64_t)8 * p.ldo * 2) = o1;
+                            continue;
+                        }
+                    }
                     if (ok) {
                         if (dbg_bits & 64) {          // experiment: non-temporal stores (the output must not evict the W panel from the L2)
                             __builtin_nontemporal_store(o0, (V8*)op);

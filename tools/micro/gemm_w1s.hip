@@ -34,7 +34,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // operations into a real [M, N] fp16 output (the previous tile's positions, a 32 x 32 block per instruction as the production epilogue writes them):
 // do a tile's 128 stores, trickled over the next tile (1.33 per wave and half-step at K = 768), hide behind the 768 LDS-DMA pieces that share the
 // wave's in-order vector-memory queue?  NS = 0 / 1 / 2 = 0 / 96 / 192 stores per tile.
-template <bool CHK, int NS>
+template <bool CHK, int NS, int SM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w1(const _Float16* __restrict__ A, const _Float16* __restrict__ W, float* __restrict__ out,
                                                   int K, int tiles_n, int tiles_total, _Float16* __restrict__ C16, int ldc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,8 +98,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w1(const _Float16* __restrict__ A
     auto trickle = [&](int h, int k) {                              // k-th dummy store of half-step h: block (2 * c_kh + k) & 15 of the wave's 4 x 4
         const int tm = c_t / tiles_n, tn = c_t - tm * tiles_n;
         const int blk = (c_kh * NS + k) & 15;
-        const char* base = (const char*)C16 + ((size_t)(tm * BM + wm * 128 + (blk >> 2) * 32) * ldc + tn * BN + wn * 128 + (blk & 3) * 32) * 2;
-        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(st_lane), "v"(bf[0][k & 3]), "s"(base) : "memory");
+        if constexpr (SM == 1) {          // a 256-KiB window per workgroup, re-written every tile: the lines never leave the L2
+            const char* base = (const char*)C16 + (size_t)blockIdx.x * 262144 + wave * 65536 + blk * 4096;
+            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"((uint32_t)(lane * 16 + (c_kh & 3) * 1024)), "v"(bf[0][k & 3]), "s"(base) : "memory");
+        } else if constexpr (SM == 2) {   // the big output, but 1 KiB contiguous per instruction
+            const char* base = (const char*)C16 + ((size_t)(tm * BM + wm * 128 + (blk >> 2) * 32) * ldc + tn * BN + wn * 128 + (blk & 3) * 32) * 2;
+            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"((uint32_t)(lane * 16)), "v"(bf[0][k & 3]), "s"(base) : "memory");
+        } else {
+            const char* base = (const char*)C16 + ((size_t)(tm * BM + wm * 128 + (blk >> 2) * 32) * ldc + tn * BN + wn * 128 + (blk & 3) * 32) * 2;
+            if constexpr (SM == 3) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(st_lane), "v"(bf[0][k & 3]), "s"(base) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(st_lane), "v"(bf[0][k & 3]), "s"(base) : "memory");
+        }
     };
     // one fragment read: q = 0..3 -> af[buf][q], 4..7 -> bf[buf][q - 4]
     auto load1 = [&](int h, int ks, int buf, int q) {
@@ -230,6 +239,24 @@ int main(int argc, char** argv) {
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("M %d N %d K %d, %d trickled stores per wave and half-step (%d per tile): %.1f us per launch, %.0f TFLOP/s\n", M, N, K, ns, ns * 4 * (K / BK), ms / 10 * 1e3, 2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12);
+    }
+    // what does a trickled store cost by DESTINATION / shape?  (NS = 1: 96 per tile)
+    CHECK(hipFuncSetAttribute((const void*)gemm_w1<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE));
+    CHECK(hipFuncSetAttribute((const void*)gemm_w1<true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE));
+    CHECK(hipFuncSetAttribute((const void*)gemm_w1<true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE));
+    const char* names[4] = {"[M,N] output, 32 rows x 2 x 16 B per instruction", "256-KiB window per workgroup, re-written every tile (L2 resident)", "[M,N] output, 1 KiB contiguous per instruction", "[M,N] output, nt"};
+    for (int rep = 0; rep < 8; ++rep) {
+        const int sm = rep % 4;
+        CHECK(hipEventRecord(e0));
+        for (int it = 0; it < 10; ++it) {
+            if (sm == 0) hipLaunchKernelGGL((gemm_w1<true, 1, 0>), dim3(256), dim3(256), NST * STAGE, 0, A, W, out, K, tiles_n, tiles, C16, N);
+            else if (sm == 1) hipLaunchKernelGGL((gemm_w1<true, 1, 1>), dim3(256), dim3(256), NST * STAGE, 0, A, W, out, K, tiles_n, tiles, C16, N);
+            else if (sm == 2) hipLaunchKernelGGL((gemm_w1<true, 1, 2>), dim3(256), dim3(256), NST * STAGE, 0, A, W, out, K, tiles_n, tiles, C16, N);
+            else hipLaunchKernelGGL((gemm_w1<true, 1, 3>), dim3(256), dim3(256), NST * STAGE, 0, A, W, out, K, tiles_n, tiles, C16, N);
+        }
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("1 store per wave and half-step -> %s: %.1f us per launch, %.0f TFLOP/s\n", names[sm], ms / 10 * 1e3, 2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12);
     }
     return 0;
 }
