@@ -55,12 +55,13 @@ def parse(argv=None):
     ap.add_argument("--dedup", action="store_true",
                     help="SURVEY 8f-3 (reported separately, never the headline): encode each distinct item id of the batch "
                          "once (padding = id 0) and scatter the taps back; images are then drawn per item id")
-    ap.add_argument("--overlap-towers", dest="overlap_towers", action="store_true", default=False,
-                    help="opt-in (`mm_encoder.overlap_towers = True`): ViT tower on a high-priority HIP stream, BERT tower on a normal-priority one "
-                         "beside it — same kernels, same results, -0.3 .. -0.4 ms per step (profiles/r5_overlap.md).  Kernels of the two towers then "
-                         "share the CUs, so per-kernel durations (events and rocprofv3 alike) stop being a kernel measure; "
-                         "`roofline.dominant_kernel` times the image tower's launches only")
-    ap.add_argument("--no-overlap-towers", dest="overlap_towers", action="store_false", help="(the default) both towers on one stream")
+    ap.add_argument("--overlap-towers", dest="overlap_towers", action="store_true", default=True,
+                    help="(the default since round 6 = the product default `mm_encoder.overlap_towers`) ViT tower on a high-priority HIP stream, "
+                         "BERT tower on a normal-priority one beside it — same kernels, bit-identical results, -0.3 .. -0.4 ms per step "
+                         "(profiles/r5_overlap.md)")
+    ap.add_argument("--no-overlap-towers", dest="overlap_towers", action="store_false",
+                    help="both towers back to back on one stream: for PROFILING runs (kernels of two overlapped towers share the CUs, so "
+                         "their per-kernel durations — HIP events and rocprofv3 alike — are not kernel measures)")
     ap.add_argument("--cached", choices=["fp32", "fp16", "bf16"], default=None,
                     help="secondary workload (BASELINE config 3, never the headline): Code_Cached IISAN fed from a "
                          "device-resident packed tap store of the given precision; use with --bs 1024")
@@ -332,7 +333,8 @@ def pmc_traffic(a):
     """Measured memory-side bytes per gemm16 launch of the DEFAULT configuration, from the committed summary of the two PMC
     passes (tools/pmc_traffic.py); PMC counters cannot be read from inside the timed run, so any other configuration
     reports null."""
-    default = (a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup and not a.overlap_towers
+    # (counter passes serialise the kernels: the per-launch bytes are those of the towers back to back, whichever way the step schedules them)
+    default = (a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup
                and not a.cached and a.chunk == 0)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not default or not os.path.exists(path):
@@ -451,15 +453,16 @@ class Uncached:
         if overlap is not None:
             enc.overlap_towers = overlap
         clock = Clock(self.dev, world)
-        # overlapped towers: only the launches on the main stream (the ViT tower) are a kernel measure (csrc/timing.cpp)
-        lib.iisan_timing_only_stream(enc.tower_streams()[0].cuda_stream if enc.overlap_towers else None, 1 if enc.overlap_towers else 0)
         try:
             # Two passes of the same K steps (round 5; the Cached line has always done this): `value` / `ms_per_step` come from a pass
-            # with NO instrumentation inside the timed region; the per-launch HIP events of `roofline.dominant_kernel` (194 event
-            # records per step on the launching stream) and the all-reduce events of a multi-rank run ride on a second pass —
-            # same-box A/B, three interleaved rounds of 20 steps: the events cost +0.34 ms per step (tools/overlap_ab.py,
-            # profiles/r5_overlap.md).
+            # with NO instrumentation inside the timed region, scheduled as the product schedules it (round 6: the two towers on two
+            # HIP streams).  The per-launch HIP events of `roofline.dominant_kernel` (194 event records per step on the launching
+            # stream) and the all-reduce events of a multi-rank run ride on a second pass with the towers BACK TO BACK on one stream:
+            # kernels of two overlapped towers share the CUs and their durations are not kernel measures
+            # (profiles/r4_overlap_by_stream.md); the events themselves cost +0.34 ms per step (profiles/r5_overlap.md).
             elapsed, loss = clock.run(self.step, warmup, steps)
+            overlapped = enc.overlap_towers
+            enc.overlap_towers = False
             if world > 1:
                 self.tr.time_allreduce = True
                 self.tr.allreduce_ms()
@@ -467,8 +470,6 @@ class Uncached:
             self.tr.time_allreduce = False
         finally:
             self.set_full_blocks(False)
-            lib.iisan_timing_only_stream(None, 0)
-            overlapped = enc.overlap_towers
             enc.overlap_towers = prev_overlap
             self.tr.time_allreduce = False
         dinfo = self.dist_info(steps) if world > 1 else None
@@ -489,9 +490,9 @@ class Uncached:
                                    f"bs={a.bs}/GPU ({slots} item slots, " + ("distinct item ids encoded once" if a.dedup else "all encoded") + "), 1xMI355X per rank",
                        "global_batch": a.bs * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
                        **({"distributed": dinfo} if dinfo else {}),
-                       "towers": ("image tower on a high-priority HIP stream, text tower on a normal-priority one beside it (same kernels, same results); "
-                                  "`roofline.dominant_kernel` times the gemm16 launches of the image tower's stream (87 % of the encoder GEMM FLOPs)") if overlapped
-                                 else "both towers on one stream; `roofline.dominant_kernel` times every gemm16 launch",
+                       "towers": ("image tower on a high-priority HIP stream, text tower on a normal-priority one beside it (the product default: same kernels, "
+                                  "bit-identical results); `roofline.dominant_kernel` is timed in a second pass with the towers back to back on one stream") if overlapped
+                                 else "both towers back to back on one stream (--no-overlap-towers: the profiling form)",
                        "encoder_blocks": "all tokens in every block" if full_blocks else
                                          "WORK PRUNING: last block computes K/V for all tokens, attention/O/MLP for the CLS rows only (only hidden_states[i][:,0] is consumed; taps identical)"},
             # SURVEY 8d's definition: the WHOLE forward+backward step against the dense 16-bit MFMA peak —
@@ -509,13 +510,13 @@ class Uncached:
                          # the dominant kernel class, measured live with HIP events on the launching stream around every launch
                          "dominant_kernel": {
                              "kernel": "gemm16 (gemm16_h256_kernel: QKV/O/FC1/FC2 GEMMs of the frozen encoders"
-                                       + (", ViT tower = the launches on the main stream" if overlapped else "") + "; flops = executed, by launch)",
+                                       "; flops = executed, by launch)",
                              "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                              "frac": gemm_tflops / (MFMA_PEAK / 1e12),
                              "launches": int(n_launch), "avg_launch_ms": ms.value / max(n_launch, 1),
                              "flop_per_launch": fl.value / max(n_launch, 1),
                              "ms_per_step": ms.value / max(steps, 1),
-                             "measured_in": f"a second pass of the same {steps} steps with HIP events around every launch ({elapsed_ev / steps * 1e3:.3f} ms per step with them)",
+                             "measured_in": f"a second pass of the same {steps} steps, towers back to back on one stream, HIP events around every launch ({elapsed_ev / steps * 1e3:.3f} ms per step that way)",
                              "traffic": traffic, "traffic_algorithmic": lib.iisan_timing_last_bytes() / max(n_launch, 1)}},
         }
 
@@ -608,7 +609,7 @@ def cpu_baseline(seed=5, bs=16, warm=3, timed=5, budget_s=100.0):
 def secondary_lines(a, unc, lib, dev, rank, world):
     """The other BASELINE configurations / ablations, a few seconds each, driver-timed inside the default run."""
     out = []
-    k, w = min(a.steps, 5), min(a.warmup, 2)
+    k, w = min(a.steps, 10), min(a.warmup, 3)
 
     def add(name, fn):
         try:
@@ -622,9 +623,8 @@ def secondary_lines(a, unc, lib, dev, rank, world):
         "on the CLS rows only (taps identical)", lambda: unc.line(k, w, "fp16", False, headline=False))
     add("uncached, bf16 encoder operands (misses the 1e-3 parity tolerance, DESIGN 3)", lambda: unc.line(k, w, "bf16", True, headline=False))
     unc.set_dtype(a.dtype)
-    add("uncached, image tower on a high-priority HIP stream with the text tower on a normal-priority one beside it (opt-in `mm_encoder.overlap_towers`; same "
-        "kernels, same results; the two towers' kernels share the CUs, so `roofline.dominant_kernel` — the image tower's gemm16 launches — is not a clean kernel measure here)",
-        lambda: unc.line(k, w, a.dtype, True, headline=False, overlap=True))
+    add("uncached with both towers back to back on one stream (`mm_encoder.overlap_towers = False`, the form every profile under profiles/ is taken in)",
+        lambda: unc.line(max(k, min(a.steps, 10)), max(w, min(a.warmup, 3)), a.dtype, True, headline=False, overlap=False))
     unc.set_dtype(a.dtype)
     c3 = argparse.Namespace(**{**vars(a), "cached": "fp32", "versa": False, "bs": 1024})
     add("BASELINE config 3: Code_Cached IISAN bs=1024, fp32 tap store", lambda: cached_line(c3, lib, dev, rank, world, 10, 3))
@@ -682,7 +682,7 @@ def main():
         if check:
             out["config"]["kernel_family_check"] = check
         default = (world == 1 and a.bs == 128 and a.dtype == "fp16" and a.full_blocks and not a.dedup
-                   and not a.overlap_towers and a.chunk == 0)
+                   and a.overlap_towers and a.chunk == 0)
         if default and not a.no_secondary:
             out["secondary"] = secondary_lines(a, unc, lib, dev, rank, world)
         if world == 1 and not a.no_cpu_baseline:

@@ -72,6 +72,8 @@ SIGNATURES = {
     "iisan_inbatch_ce_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, sz, C.POINTER(u64), vp]),
     "iisan_inbatch_ce_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, sz, u64, vp]),
     "iisan_score_rank": (i32, [vp, vp, i64, i64, i32, vp, i32, vp, vp, vp]),
+    "iisan_score_topk_ws_bytes": (sz, [i64, i64, i32]),
+    "iisan_score_topk": (i32, [vp, vp, i64, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
     "iisan_adam_step": (i32, [vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(f32), i32, i32, f32, f32, f32, f32, vp]),
     "iisan_gemm16": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "iisan_layernorm768": (i32, [i32, vp, vp, vp, f32, vp, vp, i64, vp]),
@@ -130,9 +132,16 @@ def load():
     # development aid (profiling a non-default route under rocprofv3): IISAN_DEV_KNOBS="sanb_fused=0,gemm32_k64=1" sets the named
     # development switches (include/iisan_hip.h, DEV section) once at load time.  Unset in every product, test and bench run — and
     # never silent: one stderr line says which kernels were re-routed, and bench.py copies `dev_knobs()` into its `config`.
-    for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")):
-        name, val = kv.split("=")
-        dev_set(name.strip(), int(val))
+    try:
+        for kv in filter(None, os.environ.get("IISAN_DEV_KNOBS", "").split(",")):
+            name, val = kv.split("=")
+            dev_set(name.strip(), int(val))
+    except Exception:
+        # a bad name / value must not leave a half-configured library cached behind a failed load(): the next load() would return
+        # it with the earlier switches applied and without the stderr line below
+        lib.iisan_dev_reset()
+        _lib = None
+        raise
     if dev_knobs():
         import sys
         print(f"iisan_amd: development switches {dev_knobs()!r} are set: product kernel routes are overridden for this process",

@@ -278,6 +278,12 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     const bool timed = iisan_timing_on(s);
     if (timed) iisan_timing_pre(s, 2.0 * (double)a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N));
     const int var = g_variant & 0xff;
+#ifndef GEMM16_DEBUG_BITS
+    // ablation / experiment bits (gemm16_variant = 4 | bits << 8) exist only in `make EXTRA=-DGEMM16_DEBUG_BITS` builds: a default
+    // build would run the plain product kernel and the A/B tools (tools/gemm_walk.py, gemm_stream.py, gemm_slots_h.py) would read
+    // numbers that mean nothing
+    IISAN_CHECK_SHAPE((g_variant >> 8) == 0, "gemm16: debug bits 0x%x requested, but this library was built without -DGEMM16_DEBUG_BITS", (unsigned)(g_variant >> 8));
+#endif
     const bool big = var == 3 || var == 4 || (var == 0 && ceil_div(a.M, 256) * (a.N / 256) >= 128);
     int rc;
     if (big && (var == 4 || (var == 0 && g_auto_staggered)) && gemm16_h256_applicable(mode, a)) {

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_h256_kernel(Gemm16Args p, int t
                         if (!FULL) ok = (int64_t)(mrow + frow) < p.M;
                     }
                     if constexpr (EPI == EPI_OUT16 || EPI == EPI_GELU16) {
-                        if (dbg_bits & 512) {
+                        if (FULL && (dbg_bits & 512)) {      // (full row tiles only: the re-addressed rows are not tested against M)
                             // experiment (round 5, timing only — the DATA lands in the wrong places): the same two stores per block, but each
                             // instruction writes 8 complete 128-byte rows of the wave's 64-column slice (8 cache lines) instead of two 16-byte
                             // pieces in each of 32 rows (32 lines).  What would line-complete stores be worth if the rearrangement were free?

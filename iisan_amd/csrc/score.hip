@@ -176,6 +176,223 @@ __global__ void zero_ranks_kernel(int32_t* __restrict__ r, int64_t n) {
     if (i < n) r[i] = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Recommendation list: the first k item ids of `order = argsort(score, descending)` over the history-masked score row without column 0
+// (metrics_topK, Code_Uncached/data_utils/metrics.py:59-60, on the row eval_model builds at :198-206) — what the rank above is a position in.
+// Same score tiles as score_rank_mfma_kernel (one 16-MFMA chain per score: the bits of a score are those the rank kernel compares, so a
+// target ranked r <= k sits at position r - 1 of this list), same tie rule (lower item id first = a stable descending argsort), and the
+// [U, N] scores never exist either:
+//   * every wave keeps, per user, a short candidate list in LDS and the list's k-th best entry as a register threshold; a score is
+//     appended only when it is ahead of that threshold (one compare per score in the common case);
+//   * a list that could overflow with the next tile is COMPACTED by the wave itself: entries that are in the user's exclusion list are
+//     dropped, every other entry counts the entries ahead of it (the order is total: scores, then ids) and moves to the slot of that
+//     count if it is < k — the list comes out sorted, the threshold is its last entry;
+//   * the four waves' lists meet the same way per workgroup, the item splits' lists in topk_merge_kernel: every step is a selection by
+//     exact comparisons in a fixed total order, so the result does not depend on launch geometry or timing.
+// Fewer than k candidates (item_num - |history| < k): the remaining slots hold id 0 / score -inf (the reference's argsort lists the -inf
+// items there, in ascending id order for a stable sort: iisan_amd/evaluate.py fills them in).
+constexpr int TK_MAX = 16;          // k <= 16
+constexpr int TK_CAP = 48;          // candidate slots per (wave, user): a tile appends at most 16, compaction when more than TK_CAP - 16 are used
+constexpr int TK_HS = 64;           // exclusion-list entries per user kept in LDS (longer lists are read from global memory)
+constexpr int TK_MAX_SPLITS = 128;  // item splits per user block (topk_merge_kernel stages splits * k entries in LDS)
+
+__device__ __forceinline__ int f2i(float x) { return __float_as_int(x); }
+// lanes of ONE wave exchanging data through LDS: the hardware runs a wave's LDS operations in order, the compiler must too
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one wave: drop excluded entries, select and sort the k best of cand[0 .. cnt[x]) for every user x of the workgroup
+__device__ __forceinline__ void topk_compact(float2 (*cand)[UB], float2 (*tmp)[UB], int* cnt, int lane, int k, int u0, int U,
+                                             const int (*s_hist)[TK_HS + 1], const int32_t* __restrict__ history, int hist_stride) {
+    const int x = lane & 31, half = lane >> 5;
+    const int n = cnt[x];
+    const int uu = u0 + x;
+    for (int e = half; e < n; e += 2) {                         // exclusion: `score[history] = -inf` (metrics.py:204-205)
+        const int c = f2i(cand[e][x].y);
+        bool ex = false;
+        if (hist_stride <= TK_HS) {
+            for (int h = 0; h < hist_stride; ++h) ex |= s_hist[x][h] == c;
+        } else if (uu < U) {
+            for (int h = 0; h < hist_stride; ++h) ex |= history[(int64_t)uu * hist_stride + h] == c;
+        }
+        if (ex) cand[e][x] = make_float2(-INFINITY, __int_as_float(0));
+    }
+    wave_sync();
+    int nv = 0;
+    for (int f = 0; f < n; ++f) nv += f2i(cand[f][x].y) != 0;
+    for (int e = half; e < n; e += 2) {
+        const float2 ce = cand[e][x];
+        const int c = f2i(ce.y);
+        if (c == 0) continue;
+        int r = 0;
+        for (int f = 0; f < n; ++f) {
+            const float2 cf = cand[f][x];
+            const int cc = f2i(cf.y);
+            r += (cc != 0 && ahead(cf.x, cc, ce.x, c)) ? 1 : 0;
+        }
+        if (r < k) tmp[r][x] = ce;
+    }
+    wave_sync();
+    const int m = nv < k ? nv : k;
+    for (int e = half; e < m; e += 2) cand[e][x] = tmp[e][x];
+    if (half == 0) cnt[x] = m;
+    wave_sync();
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb, int n_items,
+                                                         const int32_t* __restrict__ history, int hist_stride, int U, int tiles_per_split,
+                                                         int k, float2* __restrict__ part, int32_t* __restrict__ ids, float* __restrict__ scores) {
+    __shared__ float2 s_cand[4][TK_CAP][UB];        // 48 KiB
+    __shared__ float2 s_tmp[4][TK_MAX][UB];         // 16 KiB
+    __shared__ int s_hist[UB][TK_HS + 1];
+    __shared__ int s_cnt[4][UB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int u0 = blockIdx.x * UB;
+
+    f4 b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int uu = u0 + 16 * u + j;
+        if (uu < U) load_row16(prec + (int64_t)uu * 64, g, b[u]);
+        else
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (threadIdx.x < 4 * UB) s_cnt[threadIdx.x >> 5][threadIdx.x & 31] = 0;
+    if (hist_stride <= TK_HS)
+        for (int i = threadIdx.x; i < UB * hist_stride; i += 256) {
+            const int x = i / hist_stride, h = i - x * hist_stride;
+            s_hist[x][h] = u0 + x < U ? history[(int64_t)(u0 + x) * hist_stride + h] : 0;
+        }
+    __syncthreads();
+
+    float2 (*cand)[UB] = s_cand[wave];
+    float2 (*tmp)[UB] = s_tmp[wave];
+    int* cnt = s_cnt[wave];
+    float st[2] = {-INFINITY, -INFINITY};
+    int tt[2] = {0x7fffffff, 0x7fffffff};
+    const bool live[2] = {u0 + j < U, u0 + 16 + j < U};
+
+    const int n_tiles = (n_items + 15) >> 4;
+    const int tile_lo = blockIdx.y * tiles_per_split;
+    int tile_hi = tile_lo + tiles_per_split;
+    if (tile_hi > n_tiles) tile_hi = n_tiles;
+    f4 a[4], an[4];
+    int tile = tile_lo + wave;
+    auto row_of = [&](int tl) { int c = tl * 16 + j; return item_emb + (int64_t)(c < n_items ? c : 0) * 64; };
+    if (tile < tile_hi) load_row16(row_of(tile), g, a);
+    for (; tile < tile_hi; tile += 4) {
+        const bool more = tile + 4 < tile_hi;
+        if (more) load_row16(row_of(tile + 4), g, an);
+        f4 acc[2];
+        tile_scores(a, b, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = tile * 16 + 4 * g + r;
+            const bool item = c >= 1 && c < n_items;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (item && live[u] && ahead(acc[u][r], c, st[u], tt[u])) {
+                    const int pos = atomicAdd(&cnt[16 * u + j], 1);            // the four lanes (g) of a user append concurrently
+                    cand[pos][16 * u + j] = make_float2(acc[u][r], __int_as_float(c));
+                }
+        }
+        wave_sync();
+        if (__any(cnt[lane & 31] > TK_CAP - 16)) {
+            topk_compact(cand, tmp, cnt, lane, k, u0, U, s_hist, history, hist_stride);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int x = 16 * u + j;
+                if (cnt[x] >= k) { const float2 t = cand[k - 1][x]; st[u] = t.x; tt[u] = f2i(t.y); }
+            }
+        }
+        if (more)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[v] = an[v];
+    }
+    topk_compact(cand, tmp, cnt, lane, k, u0, U, s_hist, history, hist_stride);
+    __syncthreads();
+
+    // ---- the four waves' sorted lists -> the workgroup's k best per user: thread (x, p) takes entries p, p + 8, ... of the concatenation
+    {
+        const int x = threadIdx.x & 31, p = threadIdx.x >> 5;
+        const int uu = u0 + x;
+        const int n0 = s_cnt[0][x], n1 = s_cnt[1][x], n2 = s_cnt[2][x], n3 = s_cnt[3][x];
+        const int nall = n0 + n1 + n2 + n3;
+        auto entry = [&](int e) {
+            if (e < n0) return s_cand[0][e][x];
+            e -= n0;
+            if (e < n1) return s_cand[1][e][x];
+            e -= n1;
+            if (e < n2) return s_cand[2][e][x];
+            return s_cand[3][e - n2][x];
+        };
+        float2* dst_part = DIRECT ? nullptr : part + ((int64_t)blockIdx.y * U + uu) * k;
+        auto put = [&](int r, float2 v) {
+            if (DIRECT) { ids[(int64_t)uu * k + r] = f2i(v.y); if (scores) scores[(int64_t)uu * k + r] = v.x; }
+            else dst_part[r] = v;
+        };
+        if (uu < U) {
+            for (int e = p; e < nall; e += 8) {
+                const float2 ce = entry(e);
+                const int c = f2i(ce.y);
+                int r = 0;
+                for (int f = 0; f < nall; ++f) { const float2 cf = entry(f); r += ahead(cf.x, f2i(cf.y), ce.x, c) ? 1 : 0; }
+                if (r < k) put(r, ce);
+            }
+            for (int r = (nall < k ? nall : k) + p; r < k; r += 8) put(r, make_float2(-INFINITY, __int_as_float(0)));
+        }
+    }
+}
+
+// the item splits' lists of one user -> ids / scores (one wave per user; at most TK_MAX_SPLITS * TK_MAX entries)
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float2* __restrict__ part, int splits, int U, int k, int32_t* __restrict__ ids,
+                                                        float* __restrict__ scores) {
+    __shared__ float2 s_e[TK_MAX_SPLITS * TK_MAX];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const int n = splits * k;
+    int nv = 0;
+    for (int e = lane; e < n; e += 64) {
+        const int sp = e / k, i = e - sp * k;
+        const float2 v = part[((int64_t)sp * U + u) * k + i];
+        s_e[e] = v;
+        nv += f2i(v.y) != 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
+    __syncthreads();
+    for (int e = lane; e < n; e += 64) {
+        const float2 ce = s_e[e];
+        const int c = f2i(ce.y);
+        if (c == 0) continue;
+        int r = 0;
+        for (int f = 0; f < n; ++f) {
+            const float2 cf = s_e[f];
+            const int cc = f2i(cf.y);
+            r += (cc != 0 && ahead(cf.x, cc, ce.x, c)) ? 1 : 0;
+        }
+        if (r < k) { ids[(int64_t)u * k + r] = c; if (scores) scores[(int64_t)u * k + r] = ce.x; }
+    }
+    for (int r = (nv < k ? nv : k) + lane; r < k; r += 64) { ids[(int64_t)u * k + r] = 0; if (scores) scores[(int64_t)u * k + r] = -INFINITY; }
+}
+
+// item splits of the top-k launch: two workgroups per CU fit (64 KiB of LDS each); a wave's stream should be long against k
+static int topk_splits(int64_t U, int64_t n_items_plus1) {
+    const int64_t ublocks = ceil_div(U, UB), n_tiles = ceil_div(n_items_plus1, 16);
+    int64_t splits = ceil_div((int64_t)2 * iisan_cu_count(), ublocks);
+    if (splits > n_tiles / 64) splits = n_tiles / 64;            // at least 16 tiles (256 items) per wave
+    if (splits > TK_MAX_SPLITS) splits = TK_MAX_SPLITS;
+    if (splits < 1) splits = 1;
+    const int64_t per = ceil_div(n_tiles, splits);
+    return (int)ceil_div(n_tiles, per);
+}
+
 }  // namespace
 
 extern "C" int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
@@ -199,6 +416,45 @@ extern "C" int iisan_score_rank(const float* prec, const float* item_emb, int64_
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(score_rank_mfma_kernel, dim3((unsigned)ublocks, (unsigned)splits), dim3(256), 0, s, prec, item_emb,
                        (int)n_items_plus1, history, hist_stride, target, ranks, (int)U, per);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+extern "C" size_t iisan_score_topk_ws_bytes(int64_t U, int64_t n_items_plus1, int32_t k) {
+    if (U <= 0 || n_items_plus1 <= 1 || k <= 0) return 0;
+    const int splits = topk_splits(U, n_items_plus1);
+    return splits > 1 ? align_up((size_t)splits * (size_t)U * (size_t)k * sizeof(float2), 256) : 0;
+}
+
+extern "C" int iisan_score_topk(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
+                                const int32_t* history, int32_t hist_stride, int32_t k, int32_t* topk_ids, float* topk_scores,
+                                void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    IISAN_CHECK_SHAPE(E == 64, "score_topk: embedding_dim must be 64 (got %d)", E);
+    IISAN_CHECK_SHAPE(U > 0 && n_items_plus1 > 1 && hist_stride >= 0, "score_topk: empty problem");
+    IISAN_CHECK_SHAPE(k >= 1 && k <= TK_MAX, "score_topk: k must be in 1..%d (got %d)", TK_MAX, k);
+    IISAN_CHECK_SHAPE(hist_stride == 0 || history, "score_topk: hist_stride %d without a history array", hist_stride);
+    IISAN_CHECK_SHAPE(U < (1ll << 31) - UB && n_items_plus1 < (1ll << 31) - 16 && U * k < (1ll << 31), "score_topk: problem too large for 32-bit indices");
+    IISAN_CHECK_SHAPE((((uintptr_t)prec | (uintptr_t)item_emb) & 15) == 0, "score_topk: prec and item_emb must be 16-byte aligned");
+    const int ublocks = (int)ceil_div(U, UB);
+    const int n_tiles = (int)ceil_div(n_items_plus1, 16);
+    const int splits = topk_splits(U, n_items_plus1);
+    const int per = (int)ceil_div(n_tiles, splits);
+    const size_t need = iisan_score_topk_ws_bytes(U, n_items_plus1, k);
+    if (ws_bytes < need || (need && !ws)) {
+        iisan_set_error("score_topk: workspace too small (%zu < %zu)", ws_bytes, need);
+        return IISAN_EWORKSPACE;
+    }
+    if (splits == 1) {
+        hipLaunchKernelGGL(score_topk_kernel<true>, dim3((unsigned)ublocks, 1), dim3(256), 0, s, prec, item_emb, (int)n_items_plus1, history,
+                           hist_stride, (int)U, per, k, (float2*)nullptr, topk_ids, topk_scores);
+        IISAN_LAUNCH_OK();
+        return IISAN_OK;
+    }
+    hipLaunchKernelGGL(score_topk_kernel<false>, dim3((unsigned)ublocks, (unsigned)splits), dim3(256), 0, s, prec, item_emb, (int)n_items_plus1,
+                       history, hist_stride, (int)U, per, k, (float2*)ws, topk_ids, topk_scores);
+    IISAN_LAUNCH_OK();
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)U), dim3(64), 0, s, (const float2*)ws, splits, (int)U, k, topk_ids, topk_scores);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }

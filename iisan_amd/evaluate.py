@@ -1,5 +1,7 @@
 """Batched evaluation and tap caching on the HIP path — the callers on either side of the hot path.
 
+* `recommend_topk`  the recommendation list itself: the first k item ids of `metrics_topK`'s argsort per user
+  (`metrics.py:59-60`), selected on the device from the same score tiles as the ranks (`iisan_score_topk`).
 * `evaluate_ranks` / `hit_ndcg`  replace the per-user Python loop of `eval_model` + the full argsort of `metrics_topK`
   (`Code_Uncached/data_utils/metrics.py:59-67,157-246`): user vectors from SASRec, scores against the whole item table
   and the target's rank are computed on the device in two launches per user batch; users are sharded contiguously
@@ -154,6 +156,47 @@ def evaluate_ranks(model, item_emb: torch.Tensor, eval_seqs: Sequence[Sequence[i
         bad = torch.nonzero(ranks < 1).flatten()[:8].tolist()
         raise IndexError(f"evaluate_ranks: target item id outside 1..{item_emb.shape[0] - 1} for users {bad}")
     return ranks
+
+
+@torch.no_grad()
+def recommend_topk(model, item_emb: torch.Tensor, input_seqs: Sequence[Sequence[int]], histories: Sequence[Sequence[int]],
+                   max_seq_len: int, k: int = 10, batch: int = 1024, rank: int = 0, world: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Each user's recommendation list: (int32 ids [U, k], fp32 scores [U, k]), identical on all ranks — the first k entries of
+    `order = torch.argsort(y_score, descending=True)` that `metrics_topK` (`metrics.py:59-60`) computes for the row `eval_model`
+    builds at `metrics.py:198-206`, as item ids (position + 1).  `input_seqs[u]` = the items fed to the user encoder (the last
+    `max_seq_len` are used, `dataset.py:183-189`; for the reference's eval protocol `eval_seq[u][:-1]`), `histories[u]` = the items
+    scored -inf.  Ties towards the lower item id (a stable argsort).  Consistent with `evaluate_ranks`: a target it ranks r <= k is
+    `ids[u, r-1]`.  The [U, N] score matrix never exists (`iisan_score_topk`)."""
+    U = len(input_seqs)
+    hs = max(1, max((len(h) for h in histories), default=1))
+    idx = dp.sequential_shard(U, rank, world, batch) if world > 1 else list(range(U))
+    tok, lm, hist, _ = _pack_users([list(input_seqs[i]) + [0] for i in idx], [histories[i] for i in idx], max_seq_len, hs)
+    dev = item_emb.device
+    n_items = item_emb.shape[0] - 1
+    was_training = model.training
+    model.eval()
+    ids_out, sc_out = [], []
+    for i in range(0, len(idx), batch):
+        t, m = tok[i:i + batch].to(dev), lm[i:i + batch].to(dev)
+        prec = model.user_encoder(item_emb[t], m, None)[:, -1].contiguous()          # metrics.py:214-216
+        ids, sc = ops.score_topk(prec, item_emb, hist[i:i + batch].to(dev), k)
+        ids_out.append(ids)
+        sc_out.append(sc)
+    model.train(was_training)
+    ids, sc = torch.cat(ids_out), torch.cat(sc_out)
+    if n_items - hs < k:
+        # fewer than k items outside some user's history: the reference's argsort lists the -inf (history) items next — for a stable
+        # sort in ascending id order — and the kernel leaves those slots 0 (include/iisan_hip.h)
+        ids_c = ids.cpu()
+        for r in torch.nonzero((ids_c == 0).any(dim=1)).flatten().tolist():
+            excl = sorted({int(c) for c in histories[idx[r]] if 1 <= int(c) <= n_items})
+            free = int((ids_c[r] != 0).sum())
+            fill = excl[:k - free]
+            ids_c[r, free:free + len(fill)] = torch.tensor(fill, dtype=torch.int32)
+        ids = ids_c.to(dev)
+    if world > 1:
+        ids, sc = dp.gather_concat(ids, U), dp.gather_concat(sc, U)
+    return ids, sc
 
 
 def hit_ndcg(ranks: torch.Tensor, topk: int = 10) -> Tuple[float, float]:

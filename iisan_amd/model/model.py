@@ -93,6 +93,8 @@ class _SideNetBase(nn.Module):
 class IISANAdaptedMModel(_SideNetBase):
     """Uncached wrapper (`Code_Uncached/model/model.py:166-271`): owns the two frozen encoders."""
 
+    overlap_towers = True       # scheduling only (forward_item3): the two frozen towers on two HIP streams
+
     def __init__(self, mm_model, args):
         super().__init__()
         self.cv_encoder = mm_model.cv_encoder
@@ -115,14 +117,15 @@ class IISANAdaptedMModel(_SideNetBase):
             taps_cv = self.cv_encoder.forward_taps(sample_items_images.index_select(0, first), need).index_select(0, inverse)
             taps_text = self.bert_encoder.forward_taps(sample_items_text.index_select(0, first), need).index_select(0, inverse)
         else:
-            if getattr(self, "overlap_towers", False) and sample_items_images.is_cuda:
-                # opt-in: the two towers on two HIP streams of their own — the image tower on a HIGH-priority stream, the text tower on a
+            if self.overlap_towers and sample_items_images.is_cuda:
+                # the two towers on two HIP streams of their own — the image tower on a HIGH-priority stream, the text tower on a
                 # normal one — so that the text tower's kernels only fill what the image tower's persistent GEMMs leave free (their
-                # partial last rounds).  Same kernels, same results.  Round 5 (profiles/r5_overlap.md, same box, three interleaved rounds of
-                # 20 steps): -0.33 / -0.41 ms per step, every round; with BOTH towers at normal priority the step is bimodal (-0.5 ms or
-                # +1.2 .. +4.3 ms: a text-tower GEMM that wins a CU keeps it for its whole static tile list and the image tower's
-                # kernel waits for it).  Not the default: the gain is below the 0.8 ms the round-4 review asked for, and per-kernel
-                # durations (HIP events, rocprofv3) are inflated by the sharing (profiles/r4_overlap_by_stream.md).
+                # partial last rounds).  Same kernels, same results (tests/test_gpu_trainable.py: bit-identical embeddings).
+                # profiles/r5_overlap.md (same box, three interleaved rounds of 20 steps): -0.33 / -0.41 ms per step, every round; with
+                # BOTH towers at normal priority the step is bimodal (-0.5 ms or +1.2 .. +4.3 ms: a text-tower GEMM that wins a CU keeps
+                # it for its whole static tile list and the image tower's kernel waits for it).  Round 6: the default
+                # (`overlap_towers = False` / `bench.py --no-overlap-towers` for profiling runs: per-kernel durations of an overlapped
+                # run — HIP events and rocprofv3 alike — are inflated by the sharing, profiles/r4_overlap_by_stream.md).
                 cur = torch.cuda.current_stream()
                 hi, side = self.tower_streams()
                 side.wait_stream(cur)
@@ -141,7 +144,7 @@ class IISANAdaptedMModel(_SideNetBase):
         return self._side(taps_cv, taps_text, [need.index(l) for l in layers], need.index(0) if self.remove_first else 0)
 
     def tower_streams(self):
-        """(image-tower stream: high priority, text-tower stream: normal priority) of the opt-in `overlap_towers` mode, created on first use."""
+        """(image-tower stream: high priority, text-tower stream: normal priority) of the `overlap_towers` mode, created on first use."""
         if getattr(self, "_tower_streams", None) is None:
             self._tower_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream())
         return self._tower_streams

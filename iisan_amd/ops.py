@@ -330,6 +330,25 @@ def score_rank(prec_last: torch.Tensor, item_emb: torch.Tensor, history: torch.T
     return ranks
 
 
+def score_topk(prec_last: torch.Tensor, item_emb: torch.Tensor, history: torch.Tensor, k: int = 10):
+    """prec_last [U,E], item_emb [N+1,E], history int32 [U,Hs] (0-padded) -> (int32 ids [U,k], fp32 scores [U,k]): each user's k
+    best items outside its history, best first, ties towards the lower id (`iisan_score_topk`).  Slots beyond the number of such
+    items hold id 0 / score -inf."""
+    lib = _lib.load()
+    _need_cuda(prec_last, item_emb, history)
+    prec_last, item_emb = _f32c(prec_last), _f32c(item_emb)
+    history = history.to(torch.int32).contiguous()
+    U, dev = prec_last.shape[0], prec_last.device
+    ids = torch.empty((U, k), dtype=torch.int32, device=dev)
+    scores = torch.empty((U, k), dtype=torch.float32, device=dev)
+    nb = lib.iisan_score_topk_ws_bytes(U, item_emb.shape[0], k)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.iisan_score_topk(prec_last.data_ptr(), item_emb.data_ptr(), U, item_emb.shape[0], item_emb.shape[1],
+                                    history.data_ptr() if history.numel() else None, history.shape[1], k, ids.data_ptr(),
+                                    scores.data_ptr(), ws.data_ptr(), nb, _stream()), "iisan_score_topk")
+    return ids, scores
+
+
 def adam_step(p, g, m, v, seg_end: Sequence[int], seg_lr: Sequence[float], step: int, grad_scale: float = 1.0,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
     lib = _lib.load()

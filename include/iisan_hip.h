@@ -242,6 +242,20 @@ int iisan_score_rank(const float* prec, const float* item_emb, int64_t U, int64_
                      const int32_t* history, int32_t hist_stride, const int32_t* target, int32_t* ranks,
                      void* stream);
 
+/* The recommendation list itself (north_star "top-k indices"; SURVEY 8b `score_topk`): topk_ids int32 [U, k] = the first k item ids
+ * of `order = torch.argsort(y_score, descending=True)` in metrics_topK (Code_Uncached/data_utils/metrics.py:59-60) over the row
+ * eval_model builds at metrics.py:198-206 (history scored -inf, column 0 dropped, id = position + 1), ties towards the lower item id
+ * (= a stable descending argsort; the reference leaves tie order unspecified).  Scores come out of the same MFMA chain as
+ * iisan_score_rank's: a target that call ranks r <= k sits at topk_ids[u, r-1].  topk_scores fp32 [U, k] (nullable): the scores of
+ * those items.  history ids outside 1..item_num are ignored, any hist_stride >= 0 is accepted.  When fewer than k items remain outside
+ * a user's history the trailing slots hold id 0 / score -inf (the reference's argsort lists the -inf items there).
+ * Limits (IISAN_EBADSHAPE otherwise): E == 64, 1 <= k <= 16, prec and item_emb 16-byte aligned; workspace from
+ * iisan_score_topk_ws_bytes (0 bytes when one workgroup per 32 users covers the whole catalogue). */
+size_t iisan_score_topk_ws_bytes(int64_t U, int64_t n_items_plus1, int32_t k);
+int iisan_score_topk(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
+                     const int32_t* history, int32_t hist_stride, int32_t k, int32_t* topk_ids, float* topk_scores,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused Adam over a flat fp32 parameter buffer with per-segment learning rates (torch.optim.Adam defaults, the
  * optimiser of Code_Uncached/run.py:323-336).  seg_end (host, int64[n_seg]) are exclusive end offsets.

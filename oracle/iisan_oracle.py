@@ -336,6 +336,21 @@ def eval_ranks(prec_last: Tensor, item_emb: Tensor, histories: Sequence[Tensor],
     return torch.tensor(out, dtype=torch.int64)
 
 
+def eval_topk(prec_last: Tensor, item_emb: Tensor, histories: Sequence[Tensor], k: int = 10) -> Tensor:
+    """The first k item ids (int64 [U, k]) of each user's recommendation list: `order = argsort(score, descending)` over the
+    history-masked score row without column 0 (`metrics.py:60` on the row built at `metrics.py:202-206`), item id = position
+    in that row + 1.  Ties towards the lower item id (a STABLE descending argsort; the reference's `torch.argsort` leaves tie
+    order unspecified) — the rule `eval_ranks` pins, so `eval_topk(...)[u, r-1] == target` whenever `eval_ranks` says r <= k.
+    History items score -inf and therefore come last, in ascending id order, only when fewer than k other items exist."""
+    scores = prec_last @ item_emb.t()
+    out = []
+    for u in range(scores.shape[0]):
+        s = scores[u].clone()
+        s[histories[u]] = -math.inf
+        out.append(torch.argsort(s[1:], descending=True, stable=True)[:k] + 1)
+    return torch.stack(out)
+
+
 def hit_ndcg(ranks: Tensor, topk: int = 10) -> Tuple[Tensor, Tensor]:
     """`metrics_topK` (`metrics.py:59-67`): Hit@k = [rank<=k], nDCG@k = 1/log2(rank+1) inside the top k."""
     hit = (ranks <= topk).to(torch.float32)

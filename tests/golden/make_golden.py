@@ -12,7 +12,7 @@ inputs from `iisan_amd.synth` through, and stores INPUT CHECKSUMS + EXPECTED OUT
   e2e_small.npz       Uncached ModelMM end to end with 2-layer ViT/BERT (hidden 768): loss + gradients
   e2e_bs8.npz         the same on 8 sequences (88 item slots)
   e2e_inter.npz       the same as e2e_small with --modality inter (mm tower only)
-  eval.npz            data_utils.metrics.eval_model: Hit@10 / nDCG@10 and per-user ranks
+  eval.npz            data_utils.metrics.eval_model: Hit@10 / nDCG@10, per-user ranks and the first ten item ids of metrics_topK's own argsort
   adam_groups.json    name -> Adam group of the 146 trainable tensors under the rule of run.py:296-321
 
 Usage:  python tests/golden/make_golden.py [--only NAME]
@@ -305,12 +305,15 @@ def gen_eval():
         def info(self, *a, **k):
             pass
 
-    captured = []
+    captured, top10 = [], []
     orig = du.metrics.metrics_topK
 
     def spy(y_score, y_true, item_rank, topK, local_rank):
+        # what metrics_topK computes at metrics.py:60 — `y_score` is the history-masked score row without column 0
+        # (metrics.py:204-206), so position p of `order` is item id order[p] + 1: the user's recommendation list
         order = torch.argsort(y_score, descending=True)
         captured.append(int(torch.sum(torch.take(y_true, order) * item_rank).item()))
+        top10.append((order[:10] + 1).numpy().astype(np.int32))
         return orig(y_score, y_true, item_rank, topK, local_rank)
 
     du.metrics.metrics_topK = spy
@@ -324,7 +327,7 @@ def gen_eval():
                         table_cv=tables[0].numpy(), table_text=tables[1].numpy(), table_mm=tables[2].numpy(),
                         seq_flat=np.concatenate([np.array(seqs[u]) for u in range(n_users)]),
                         seq_len=np.array([len(seqs[u]) for u in range(n_users)]),
-                        ranks=ranks, hit10=hit10, ndcg10=ndcg10)
+                        ranks=ranks, hit10=hit10, ndcg10=ndcg10, top10=np.stack(top10[:n_users]))
     print(f"eval: Hit@10 {hit10:.4f} nDCG@10 {ndcg10:.4f} (ranks min {ranks.min()} max {ranks.max()})")
 
 

@@ -591,13 +591,16 @@ def test_batched_eval_pipeline_matches_reference_metrics():
 
 
 def test_overlapped_towers_give_identical_embeddings():
-    """`mm_encoder.overlap_towers` (text tower on a second HIP stream) is a scheduling choice only."""
+    """`mm_encoder.overlap_towers` (the product default since round 6: image tower on a high-priority HIP stream, text tower on a
+    normal-priority one beside it) is a scheduling choice only: bit-identical to both towers back to back on one stream."""
     z, vw, bw, b, P = gio.e2e_small_inputs()
     args = helpers.make_args(side_adapter_vit_list="0,1", side_adapter_bert_list="0,1", num_words_title=8)
     model = helpers.build_model(args, 40, b.pop_prob, vw, gio.E2E_VIT, bw, gio.E2E_BERT, cached=False)
     helpers.load_trainables(model, P)
     model.eval()
     img, txt = b.images.cuda(), b.text.cuda()
+    assert model.mm_encoder.overlap_towers is True, "the product default"
+    model.mm_encoder.overlap_towers = False
     cv0, (tx0, mm0) = model.mm_encoder(img, txt)
     model.mm_encoder.overlap_towers = True
     for _ in range(3):

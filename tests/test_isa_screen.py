@@ -9,6 +9,7 @@ import os
 import re
 import shutil
 import subprocess
+import tempfile
 
 import pytest
 
@@ -16,20 +17,54 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "iisan_amd", "csrc")
 
 
-def _kernel_meta(src, tmp_path):
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    out = tmp_path / (os.path.basename(src) + ".s")
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(out)],
-                          stderr=subprocess.DEVNULL)
-    txt = out.read_text()
+_ASM = {}
+
+
+def _asm(src):
+    """gfx950 assembly of one kernel file (cached: several tests read the same file)."""
+    if src not in _ASM:
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("hipcc not available")
+        out = os.path.join(tempfile.mkdtemp(prefix="iisan_isa_"), os.path.basename(src) + ".s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", out],
+                              stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            _ASM[src] = f.read()
+        shutil.rmtree(os.path.dirname(out), ignore_errors=True)
+    return _ASM[src]
+
+
+def _kernel_meta(src, tmp_path=None):
+    txt = _asm(src)
     meta = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", txt, re.S):
         get = lambda k: int(re.search(k + r":\s*(\d+)", m.group(2)).group(1))
         meta[m.group(1)] = dict(vgpr=get(r"\.vgpr_count"), vgpr_spill=get(r"\.vgpr_spill_count"), sgpr_spill=get(r"\.sgpr_spill_count"),
                                 scratch=get(r"\.private_segment_fixed_size"))
     return meta, txt
+
+
+def _opsel_sites(txt):
+    """Line numbers of packed fp32 VALU operations whose LOW result takes the HIGH half of an operand pair (`op_sel:[..1..]`) within three
+    instructions behind an `s_waitcnt ... lgkmcnt` — the one instruction form that returned wrong results on MI355X (a
+    compiler-generated `v_pk_fma_f32 v[..], v[st], v[..] op_sel:[0,1,0]` broadcasting a just-delivered `ds_read` result gave ZERO products
+    in a few thousand of 8.5e8 outputs per launch; with the statistic materialised as a register pair first: clean ever since)."""
+    lines = txt.split("\n")
+    sites = []
+    for i, l in enumerate(lines):
+        if not (re.search(r"v_pk_(fma|mul|add)_f32", l) and re.search(r"op_sel:\[[01,]*1", l)):
+            continue
+        k, seen = i - 1, 0
+        while k > 0 and seen < 3:
+            t = lines[k].strip()
+            if t and not t.startswith(";") and not t.startswith(".") and not t.endswith(":"):
+                seen += 1
+                if "s_waitcnt" in t and "lgkmcnt" in t:
+                    sites.append(i + 1)
+                    break
+            k -= 1
+    return sites
 
 
 def test_encoder_gemm_instantiations_have_no_scratch_and_no_spilled_vgpr(tmp_path):
@@ -55,3 +90,26 @@ def test_attention_instantiations_have_no_scratch_and_keep_two_waves_per_simd(tm
     # branches around it were gone: the hazard recognizer does not look inside inline asm)
     src = open(os.path.join(CSRC, "attn16.hip")).read()
     assert 'asm("v_min_f32' not in src and "__builtin_amdgcn_fmed3f" in src
+
+
+@pytest.mark.parametrize("name", ["gemm16_h256.hip", "attn16.hip", "rowops.hip", "encoders.hip"])
+def test_no_packed_fp32_op_sel_broadcast_straight_behind_an_lds_wait(name):
+    """VERDICT r5 weak #7 / ADVICE r4: the LayerNorm-epilogue oddity of DESIGN 6g is fixed empirically (the row statistic is
+    materialised as a register pair before the `v_pk_fma_f32`), not root-caused — so a compiler bump could re-create the failing form
+    silently between two runs of the every-element test (tools/gemm_lna.py).  This screen fails the CPU suite the moment hipcc emits
+    that form again in any kernel file of the headline's encoder path (tools/isa_opsel_scan.py runs the same scan over every file)."""
+    sites = _opsel_sites(_asm(os.path.join(CSRC, name)))
+    assert not sites, f"{name}: hi->lo op_sel packed fp32 operations straight behind an lgkmcnt wait at assembly lines {sites[:8]}"
+
+
+def test_the_op_sel_screen_recognises_the_failing_form():
+    bad = """\tds_read_b32 v10, v2
+\ts_waitcnt lgkmcnt(0)
+\tv_pk_fma_f32 v[4:5], v[10:11], v[6:7], v[8:9] op_sel:[0,1,0] op_sel_hi:[1,1,1]
+"""
+    good = """\ts_waitcnt lgkmcnt(0)
+\tv_mov_b32 v11, v10
+\tv_pk_fma_f32 v[4:5], v[10:11], v[6:7], v[8:9] op_sel_hi:[1,1,1]
+\tv_pk_mul_f32 v[4:5], v[10:11], v[6:7] op_sel_hi:[1,0]
+"""
+    assert _opsel_sites(bad) == [3] and _opsel_sites(good) == []

@@ -152,6 +152,37 @@ def test_eval_ranks_match_reference():
     assert abs(float(ndcg.mean()) - float(z["ndcg10"])) < 1e-6
 
 
+def test_eval_topk_matches_the_reference_argsort():
+    """The oracle's recommendation list (`O.eval_topk`: stable descending argsort of the history-masked row, metrics.py:59-67,
+    198-207) against the first ten positions of the reference's OWN `torch.argsort` inside `metrics_topK`, captured while
+    `eval_model` ran unmodified (tests/golden/make_golden.py: gen_eval).  300 items, 50 users: no score ties, so the
+    reference's unspecified tie order does not enter."""
+    z, seqs, tables, P = gio.eval_inputs()
+    item_emb = torch.nn.functional.linear(torch.cat(tables, 1), P["com_dense.weight"], P["com_dense.bias"])
+    S = 10
+    rows, masks, hist = [], [], []
+    for seq in seqs:
+        tokens = seq[:-1]
+        pad = S - len(tokens)
+        rows.append(item_emb[[0] * pad + tokens])
+        masks.append([0.0] * pad + [1.0] * len(tokens))
+        hist.append(torch.tensor(tokens))
+    prec = O.sasrec(torch.stack(rows), torch.tensor(masks), P, 2, 2)[:, -1]
+    top = O.eval_topk(prec, item_emb, hist, 10)
+    assert torch.equal(top, torch.from_numpy(z["top10"]).long())
+    # consistent with the rank oracle: a target ranked r <= 10 sits at position r - 1 of the list
+    tgt = torch.tensor([s[-1] for s in seqs])
+    ranks = O.eval_ranks(prec, item_emb, hist, tgt)
+    for u in range(len(seqs)):
+        if int(ranks[u]) <= 10:
+            assert int(top[u, int(ranks[u]) - 1]) == int(tgt[u])
+    # history items never appear; fewer than k candidates: the excluded items follow in ascending id order
+    for u, h in enumerate(hist):
+        assert not set(top[u].tolist()) & set(h.tolist())
+    tiny = O.eval_topk(prec[:1], item_emb[:6], [torch.tensor([2, 4])], 5)
+    assert sorted(tiny[0, :3].tolist()) == [1, 3, 5] and tiny[0, 3:].tolist() == [2, 4]
+
+
 @pytest.mark.parametrize("variant", ["text_wide_long", "image_wide_long", "equal_rmfirst"])
 def test_versa_side_network_matches_reference(variant):
     z, b, taps_cv, taps_tx, args, model, P = gio.versa_inputs(variant)

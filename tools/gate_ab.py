@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of a 0/1 route knob of the library (default: the gate-folded dF product, iisan_set_gemm32_k64_gate; `python tools/gate_ab.py
+"""A/B of a 0/1 route knob of the library (default: the gate-folded dF product, dev switch gemm32_k64_gate; `python tools/gate_ab.py
 gemm32_n64f` for the fusion-fed down projection) on the Cached step
 (bs = 1024), all slots and distinct ids, and on the Versa step; one process, interleaved rounds."""
 import contextlib

@@ -9,7 +9,7 @@ from iisan_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 import ctypes
 _probe = ctypes.CDLL(_lib.LIB_PATH)          # older builds lack newer tooling symbols: bind what exists
-for _t in (_lib.SIGNATURES, _lib.EXTRA_SIGNATURES):
+for _t in (_lib.SIGNATURES,):
     for _n in [n for n in _t if not hasattr(_probe, n)]: del _t[_n]
 lib = _lib.load()
 M = 277376
