@@ -209,6 +209,7 @@ def cached_line(a, lib, dev, rank, world, steps, warmup):
     distinct = int(torch.unique(ids).numel())
     value = slots * world * steps / elapsed
     st = model.tap_stores
+    n_params = int(sum(p.numel() for p in model.parameters() if p.requires_grad))
     return {
         "metric": f"items/s (fwd+bwd) {name}, packed device tap store, Scientific-shaped", "value": value,
         "unit": "items/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -222,7 +223,13 @@ def cached_line(a, lib, dev, rank, world, steps, warmup):
                      "frac": value / world * alg / HBM_PEAK,
                      # HBM-side bytes of one WHOLE step from the committed PMC passes of this configuration (null for others)
                      "traffic": cached_pmc_traffic(a), "traffic_algorithmic": alg * slots,
-                     "note": f"whole step against the algorithmic {alg:.0f} B/slot of SURVEY 8d (tap reads only)",
+                     # SURVEY 8d's denominator counts the tap reads only; a step also has to move its trainable state —
+                     # every parameter read by the forward and by the backward pass, its gradient written and read, and Adam's p / m / v read and
+                     # written: 11 fp32 words per parameter — which at Versa's bs = 128 (69.7 M parameters) is ten times the tap bytes
+                     "traffic_floor_incl_optimizer": alg * slots + 44.0 * n_params,
+                     "trainable_parameters": n_params,
+                     "note": f"whole step against the algorithmic {alg:.0f} B/slot of SURVEY 8d (tap reads only); `traffic_floor_incl_optimizer` adds 44 B per "
+                             "trainable parameter (weights read forward + backward, gradient written + read, Adam p/m/v read + written)",
                      # what the step is actually bound by: the f32-matrix-core GEMM family of gemm32.hip (SANB products, weight
                      # gradients, heads; HIP events around every launch of the family on its stream inside the timed region)
                      "dominant_kernels": {"kernel": "gemm32.hip family (gemm32_kernel / gemm32_k64_kernel / gemm32_n64f_kernel / "
@@ -306,6 +313,17 @@ def eval_line(a, lib, dev, rank, world, reps=5):
     torch.cuda.synchronize()
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
     flops = 2.0 * U * n * 64
+    # the recommendation list (round 6: `iisan_score_topk`, k = 10): the same score tiles, selection instead of counting — end to end
+    # (`evaluate.recommend_topk`: host packing + SASRec + the kernel) and the kernel alone
+    t_top, (top_ids, _) = wall(lambda: evaluate.recommend_topk(model, table, hists, hists, max_seq_len=10, k=10, batch=4096, rank=rank, world=world))
+    for _ in range(2):
+        ops.score_topk(prec, table, hist, 10)
+    for e0, e1 in ev:
+        e0.record()
+        ops.score_topk(prec, table, hist, 10)
+        e1.record()
+    torch.cuda.synchronize()
+    ms_top = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
     return {
         "metric": "users/s, eval path (SASRec + scores against every item + history mask + exact target rank), Scientific size",
         "value": U * world / t_e2e, "unit": "users/s", "n_gpus": world, "steps": reps, "warmup": 1,
@@ -317,7 +335,12 @@ def eval_line(a, lib, dev, rank, world, reps=5):
                    "item_table": {"items_per_s": (n + 1) / t_tab, "ms": t_tab * 1e3,
                                   "what": f"item_table: side network + com_dense forward over {n + 1} items from cached taps "
                                           "[N, 13, 768] fp32 x 2 (reference layout), item batch 2048"},
-                   "score_rank_alone": {"users_per_s": U / (ms * 1e-3), "ms_per_launch": ms, "launch": f"{U} users x {n + 1} items"}},
+                   "score_rank_alone": {"users_per_s": U / (ms * 1e-3), "ms_per_launch": ms, "launch": f"{U} users x {n + 1} items"},
+                   "recommend_topk": {"users_per_s": U * world / t_top, "ms": t_top * 1e3, "k": 10,
+                                      "what": "evaluate.recommend_topk end to end: each user's ten best items outside its history (ids + scores)",
+                                      "score_topk_alone": {"users_per_s": U / (ms_top * 1e-3), "ms_per_call": ms_top,
+                                                           "achieved_tflops": flops / (ms_top * 1e-3) / 1e12,
+                                                           "launch": f"{U} users x {n + 1} items, k = 10 (selection kernel + merge of the item splits)"}}},
         "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": flops / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": eval_pmc_traffic(a, world), "kernel": "score_rank_mfma_kernel",
                      "launches": len(ev), "avg_launch_ms": ms, "flop_per_launch": flops,
