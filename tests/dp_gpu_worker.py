@@ -78,8 +78,13 @@ def main():
         hists.append(s[:-1])
     r_w = evaluate.evaluate_ranks(model, tab_1, seqs, hists, max_seq_len=10, batch=4, rank=rank, world=world)
     r_1 = evaluate.evaluate_ranks(model, tab_1, seqs, hists, max_seq_len=10, batch=4, rank=0, world=1)
+    # ... and so are the recommendation lists (users sharded, gathered everywhere), consistent with the ranks
+    t_w, s_w = evaluate.recommend_topk(model, tab_1, [s[:-1] for s in seqs], hists, max_seq_len=10, k=5, batch=4, rank=rank, world=world)
+    t_1, s_1 = evaluate.recommend_topk(model, tab_1, [s[:-1] for s in seqs], hists, max_seq_len=10, k=5, batch=4, rank=0, world=1)
+    consistent = all(int(t_1[u, int(r_1[u]) - 1]) == seqs[u][-1] for u in range(len(seqs)) if 1 <= int(r_1[u]) <= 5)
     out.update(table_equal=bool(torch.allclose(tab_w, tab_1, rtol=1e-6, atol=1e-7)), ranks_equal=bool(torch.equal(r_w.cpu(), r_1.cpu())),
-               n_ranks=int(r_w.numel()))
+               n_ranks=int(r_w.numel()),
+               topk_equal=bool(torch.equal(t_w.cpu(), t_1.cpu()) and torch.equal(s_w.cpu(), s_1.cpu())) and consistent)
     torch.save(out, os.path.join(os.environ["DP_OUT"], f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -113,7 +113,7 @@ def _check(dumps, world):
     assert big.sum() > 0.5 * (mean != 0).sum()
     assert (got[big] - upd[big]).abs().max().item() < 1e-3 * max(d0["seg_lr"])
     for d in dumps:
-        assert d["table_equal"] and d["ranks_equal"] and d["n_ranks"] == 23
+        assert d["table_equal"] and d["ranks_equal"] and d["n_ranks"] == 23 and d["topk_equal"]
         assert all(torch.isfinite(torch.tensor(d["losses"])))
 
 
