@@ -197,7 +197,21 @@ constexpr int TK_CAP = 48;          // candidate slots per (wave, user): a tile 
 constexpr int TK_HS = 64;           // exclusion-list entries per user kept in LDS (longer lists are read from global memory)
 constexpr int TK_MAX_SPLITS = 128;  // item splits per user block (topk_merge_kernel stages splits * k entries in LDS)
 
-__device__ __forceinline__ int f2i(float x) { return __float_as_int(x); }
+// A candidate is ONE 64-bit key: the score's bits mapped monotonically to unsigned (high word), ~id (low word) — `a is ahead of b`
+// (higher score, or equal score and lower id: `ahead` above) is the single unsigned compare key(a) > key(b); 0 marks an empty / excluded
+// slot (every real key is larger).  -0.0 is canonicalised to +0.0 first: the two compare equal as floats and must tie on the id.
+typedef unsigned long long tkey;
+__device__ __forceinline__ tkey tk_key(float s, int c) {
+    uint32_t b = __float_as_uint(s + 0.0f);
+    b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+    return ((tkey)b << 32) | (uint32_t)(~c);
+}
+__device__ __forceinline__ int tk_id(tkey k) { return (int)~(uint32_t)k; }
+__device__ __forceinline__ float tk_score(tkey k) {
+    uint32_t b = (uint32_t)(k >> 32);
+    b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;
+    return __uint_as_float(b);
+}
 // lanes of ONE wave exchanging data through LDS: the hardware runs a wave's LDS operations in order, the compiler must too
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -205,50 +219,62 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one wave: drop excluded entries, select and sort the k best of cand[0 .. cnt[x]) for every user x of the workgroup
-__device__ __forceinline__ void topk_compact(float2 (*cand)[UB], float2 (*tmp)[UB], int* cnt, int lane, int k, int u0, int U,
-                                             const int (*s_hist)[TK_HS + 1], const int32_t* __restrict__ history, int hist_stride) {
+// One wave: drop the excluded entries of cand[0 .. n) of user x = lane & 31, select and sort its k best (n = this lane's user's count; lanes
+// l and l + 32 serve the same user and split its entries).  Returns the user's new count.  Cost: every entry counts the entries ahead of it —
+// one 8-byte LDS read (the 32 users side by side: conflict-free), one 64-bit compare and one add-with-carry per pair, the reads requested
+// eight at a time.  (The first version compared (score, id) pairs with one dependent LDS read per step: 1.6 ms per Scientific eval pass,
+// matrix pipe 13 % busy, waves parked 52 % of the time — profiles/r6_eval_kernel_stats.md tells the before / after.)
+__device__ __forceinline__ int topk_compact(tkey (*cand)[UB], tkey (*tmp)[UB], int n, int lane, int k, int u0, int U,
+                                            const int (*s_hist)[TK_HS + 1], const int32_t* __restrict__ history, int hist_stride) {
     const int x = lane & 31, half = lane >> 5;
-    const int n = cnt[x];
     const int uu = u0 + x;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
+    nmax = (nmax + 7) & ~7;                                      // wave-uniform, <= TK_CAP
+    int n_ex = 0;
     for (int e = half; e < n; e += 2) {                         // exclusion: `score[history] = -inf` (metrics.py:204-205)
-        const int c = f2i(cand[e][x].y);
+        const int c = tk_id(cand[e][x]);
         bool ex = false;
         if (hist_stride <= TK_HS) {
+#pragma unroll 4
             for (int h = 0; h < hist_stride; ++h) ex |= s_hist[x][h] == c;
         } else if (uu < U) {
+#pragma unroll 4
             for (int h = 0; h < hist_stride; ++h) ex |= history[(int64_t)uu * hist_stride + h] == c;
         }
-        if (ex) cand[e][x] = make_float2(-INFINITY, __int_as_float(0));
+        if (ex) { cand[e][x] = 0; ++n_ex; }
     }
+    for (int e = n + half; e < nmax; e += 2) cand[e][x] = 0;    // the tail up to the wave's longest list: stale slots must not count
+    n_ex += __shfl_xor(n_ex, 32, 64);
     wave_sync();
-    int nv = 0;
-    for (int f = 0; f < n; ++f) nv += f2i(cand[f][x].y) != 0;
     for (int e = half; e < n; e += 2) {
-        const float2 ce = cand[e][x];
-        const int c = f2i(ce.y);
-        if (c == 0) continue;
+        const tkey ke = cand[e][x];
+        if (ke == 0) continue;
         int r = 0;
-        for (int f = 0; f < n; ++f) {
-            const float2 cf = cand[f][x];
-            const int cc = f2i(cf.y);
-            r += (cc != 0 && ahead(cf.x, cc, ce.x, c)) ? 1 : 0;
+        for (int f0 = 0; f0 < nmax; f0 += 8) {
+            tkey kf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = cand[f0 + i][x];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r += kf[i] > ke ? 1 : 0;
         }
-        if (r < k) tmp[r][x] = ce;
+        if (r < k) tmp[r][x] = ke;
     }
     wave_sync();
+    const int nv = n - n_ex;
     const int m = nv < k ? nv : k;
     for (int e = half; e < m; e += 2) cand[e][x] = tmp[e][x];
-    if (half == 0) cnt[x] = m;
     wave_sync();
+    return m;
 }
 
 template <bool DIRECT>
 __global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb, int n_items,
                                                          const int32_t* __restrict__ history, int hist_stride, int U, int tiles_per_split,
-                                                         int k, float2* __restrict__ part, int32_t* __restrict__ ids, float* __restrict__ scores) {
-    __shared__ float2 s_cand[4][TK_CAP][UB];        // 48 KiB
-    __shared__ float2 s_tmp[4][TK_MAX][UB];         // 16 KiB
+                                                         int k, tkey* __restrict__ part, int32_t* __restrict__ ids, float* __restrict__ scores) {
+    __shared__ tkey s_cand[4][TK_CAP][UB];          // 48 KiB
+    __shared__ tkey s_tmp[4][TK_MAX][UB];           // 16 KiB
     __shared__ int s_hist[UB][TK_HS + 1];
     __shared__ int s_cnt[4][UB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -264,7 +290,6 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict
 #pragma unroll
             for (int v = 0; v < 4; ++v) b[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
     }
-    if (threadIdx.x < 4 * UB) s_cnt[threadIdx.x >> 5][threadIdx.x & 31] = 0;
     if (hist_stride <= TK_HS)
         for (int i = threadIdx.x; i < UB * hist_stride; i += 256) {
             const int x = i / hist_stride, h = i - x * hist_stride;
@@ -272,12 +297,22 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict
         }
     __syncthreads();
 
-    float2 (*cand)[UB] = s_cand[wave];
-    float2 (*tmp)[UB] = s_tmp[wave];
-    int* cnt = s_cnt[wave];
+    tkey (*cand)[UB] = s_cand[wave];
+    tkey (*tmp)[UB] = s_tmp[wave];
     float st[2] = {-INFINITY, -INFINITY};
     int tt[2] = {0x7fffffff, 0x7fffffff};
+    int cnt[2] = {0, 0};                                         // list lengths of users j and 16 + j: the same value in the four lanes (g) of a j
     const bool live[2] = {u0 + j < U, u0 + 16 + j < U};
+    const unsigned long long below = (1ull << (16 * g)) - 1;     // the lanes (j, g' < g)
+
+    auto compact = [&]() {
+        const int m = topk_compact(cand, tmp, (lane & 16) ? cnt[1] : cnt[0], lane, k, u0, U, s_hist, history, hist_stride);
+        cnt[0] = __shfl(m, j, 64);                               // lane x = j serves user j, lane 16 + j user 16 + j
+        cnt[1] = __shfl(m, 16 + j, 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (cnt[u] >= k) { const tkey t = cand[k - 1][16 * u + j]; st[u] = tk_score(t); tt[u] = tk_id(t); }
+    };
 
     const int n_tiles = (n_items + 15) >> 4;
     const int tile_lo = blockIdx.y * tiles_per_split;
@@ -297,26 +332,23 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict
             const int c = tile * 16 + 4 * g + r;
             const bool item = c >= 1 && c < n_items;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (item && live[u] && ahead(acc[u][r], c, st[u], tt[u])) {
-                    const int pos = atomicAdd(&cnt[16 * u + j], 1);            // the four lanes (g) of a user append concurrently
-                    cand[pos][16 * u + j] = make_float2(acc[u][r], __int_as_float(c));
-                }
-        }
-        wave_sync();
-        if (__any(cnt[lane & 31] > TK_CAP - 16)) {
-            topk_compact(cand, tmp, cnt, lane, k, u0, U, s_hist, history, hist_stride);
-#pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int x = 16 * u + j;
-                if (cnt[x] >= k) { const float2 t = cand[k - 1][x]; st[u] = t.x; tt[u] = f2i(t.y); }
+                // append without atomics: the four lanes (g) of a user learn from one ballot how many of them pass and where each one's
+                // entry goes; exclusion lists are applied at compaction (all 64 lanes busy there, one or two here)
+                const bool pass = item && live[u] && ahead(acc[u][r], c, st[u], tt[u]);
+                const unsigned long long m4 = (__ballot(pass) >> j) & 0x0001000100010001ull;
+                if (pass) cand[cnt[u] + __popcll(m4 & below)][16 * u + j] = tk_key(acc[u][r], c);
+                cnt[u] += __popcll(m4);
             }
         }
+        if (__any(cnt[0] > TK_CAP - 16 || cnt[1] > TK_CAP - 16)) { wave_sync(); compact(); }
         if (more)
 #pragma unroll
             for (int v = 0; v < 4; ++v) a[v] = an[v];
     }
-    topk_compact(cand, tmp, cnt, lane, k, u0, U, s_hist, history, hist_stride);
+    wave_sync();
+    compact();
+    if (lane < 32) s_cnt[wave][lane] = (lane & 16) ? cnt[1] : cnt[0];
     __syncthreads();
 
     // ---- the four waves' sorted lists -> the workgroup's k best per user: thread (x, p) takes entries p, p + 8, ... of the concatenation
@@ -333,63 +365,70 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const float* __restrict
             if (e < n2) return s_cand[2][e][x];
             return s_cand[3][e - n2][x];
         };
-        float2* dst_part = DIRECT ? nullptr : part + ((int64_t)blockIdx.y * U + uu) * k;
-        auto put = [&](int r, float2 v) {
-            if (DIRECT) { ids[(int64_t)uu * k + r] = f2i(v.y); if (scores) scores[(int64_t)uu * k + r] = v.x; }
+        tkey* dst_part = DIRECT ? nullptr : part + ((int64_t)blockIdx.y * U + uu) * k;
+        auto put = [&](int r, tkey v) {
+            if (DIRECT) { ids[(int64_t)uu * k + r] = v ? tk_id(v) : 0; if (scores) scores[(int64_t)uu * k + r] = v ? tk_score(v) : -INFINITY; }
             else dst_part[r] = v;
         };
         if (uu < U) {
             for (int e = p; e < nall; e += 8) {
-                const float2 ce = entry(e);
-                const int c = f2i(ce.y);
+                const tkey ke = entry(e);
                 int r = 0;
-                for (int f = 0; f < nall; ++f) { const float2 cf = entry(f); r += ahead(cf.x, f2i(cf.y), ce.x, c) ? 1 : 0; }
-                if (r < k) put(r, ce);
+                for (int f = 0; f < nall; ++f) r += entry(f) > ke ? 1 : 0;
+                if (r < k) put(r, ke);
             }
-            for (int r = (nall < k ? nall : k) + p; r < k; r += 8) put(r, make_float2(-INFINITY, __int_as_float(0)));
+            for (int r = (nall < k ? nall : k) + p; r < k; r += 8) put(r, 0);
         }
     }
 }
 
 // the item splits' lists of one user -> ids / scores (one wave per user; at most TK_MAX_SPLITS * TK_MAX entries)
-__global__ __launch_bounds__(64) void topk_merge_kernel(const float2* __restrict__ part, int splits, int U, int k, int32_t* __restrict__ ids,
+__global__ __launch_bounds__(64) void topk_merge_kernel(const tkey* __restrict__ part, int splits, int U, int k, int32_t* __restrict__ ids,
                                                         float* __restrict__ scores) {
-    __shared__ float2 s_e[TK_MAX_SPLITS * TK_MAX];
+    __shared__ tkey s_e[TK_MAX_SPLITS * TK_MAX];
     const int u = blockIdx.x, lane = threadIdx.x;
     const int n = splits * k;
     int nv = 0;
     for (int e = lane; e < n; e += 64) {
         const int sp = e / k, i = e - sp * k;
-        const float2 v = part[((int64_t)sp * U + u) * k + i];
+        const tkey v = part[((int64_t)sp * U + u) * k + i];
         s_e[e] = v;
-        nv += f2i(v.y) != 0;
+        nv += v != 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
     __syncthreads();
     for (int e = lane; e < n; e += 64) {
-        const float2 ce = s_e[e];
-        const int c = f2i(ce.y);
-        if (c == 0) continue;
+        const tkey ke = s_e[e];
+        if (ke == 0) continue;
         int r = 0;
-        for (int f = 0; f < n; ++f) {
-            const float2 cf = s_e[f];
-            const int cc = f2i(cf.y);
-            r += (cc != 0 && ahead(cf.x, cc, ce.x, c)) ? 1 : 0;
-        }
-        if (r < k) { ids[(int64_t)u * k + r] = c; if (scores) scores[(int64_t)u * k + r] = ce.x; }
+        for (int f = 0; f < n; ++f) r += s_e[f] > ke ? 1 : 0;
+        if (r < k) { ids[(int64_t)u * k + r] = tk_id(ke); if (scores) scores[(int64_t)u * k + r] = tk_score(ke); }
     }
     for (int r = (nv < k ? nv : k) + lane; r < k; r += 64) { ids[(int64_t)u * k + r] = 0; if (scores) scores[(int64_t)u * k + r] = -INFINITY; }
 }
 
-// item splits of the top-k launch: two workgroups per CU fit (64 KiB of LDS each); a wave's stream should be long against k
+// item splits of the top-k launch: two workgroups per CU fit (73 KiB of LDS each).  Longer item streams per wave mean fewer appended
+// candidates (a stream's threshold is its own k-th best), more splits mean better-filled rounds: among 1 .. 8 splits (more only when
+// there are fewer user blocks than workgroup slots) the count with the best-filled last round wins, ties to the fewer splits.
 static int topk_splits(int64_t U, int64_t n_items_plus1) {
-    const int64_t ublocks = ceil_div(U, UB), n_tiles = ceil_div(n_items_plus1, 16);
-    int64_t splits = ceil_div((int64_t)2 * iisan_cu_count(), ublocks);
-    if (splits > n_tiles / 64) splits = n_tiles / 64;            // at least 16 tiles (256 items) per wave
-    if (splits > TK_MAX_SPLITS) splits = TK_MAX_SPLITS;
-    if (splits < 1) splits = 1;
-    const int64_t per = ceil_div(n_tiles, splits);
+    const int64_t ublocks = ceil_div(U, UB), n_tiles = ceil_div(n_items_plus1, 16), slots = (int64_t)2 * iisan_cu_count();
+    int64_t cap = n_tiles / 64;                                  // at least 16 tiles (256 items) per wave
+    if (cap > TK_MAX_SPLITS) cap = TK_MAX_SPLITS;
+    if (cap < 1) cap = 1;
+    int64_t best = 1;
+    if (ublocks >= slots) {
+        double best_fill = 0.0;
+        for (int64_t sp = 1; sp <= 8 && sp <= cap; ++sp) {
+            const int64_t wgs = ublocks * sp;
+            const double fill = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
+            if (fill > best_fill + 0.02) { best_fill = fill; best = sp; }
+        }
+    } else {
+        best = ceil_div(slots, ublocks);
+        if (best > cap) best = cap;
+    }
+    const int64_t per = ceil_div(n_tiles, best);
     return (int)ceil_div(n_tiles, per);
 }
 
@@ -423,7 +462,7 @@ extern "C" int iisan_score_rank(const float* prec, const float* item_emb, int64_
 extern "C" size_t iisan_score_topk_ws_bytes(int64_t U, int64_t n_items_plus1, int32_t k) {
     if (U <= 0 || n_items_plus1 <= 1 || k <= 0) return 0;
     const int splits = topk_splits(U, n_items_plus1);
-    return splits > 1 ? align_up((size_t)splits * (size_t)U * (size_t)k * sizeof(float2), 256) : 0;
+    return splits > 1 ? align_up((size_t)splits * (size_t)U * (size_t)k * sizeof(tkey), 256) : 0;
 }
 
 extern "C" int iisan_score_topk(const float* prec, const float* item_emb, int64_t U, int64_t n_items_plus1, int32_t E,
@@ -447,14 +486,14 @@ extern "C" int iisan_score_topk(const float* prec, const float* item_emb, int64_
     }
     if (splits == 1) {
         hipLaunchKernelGGL(score_topk_kernel<true>, dim3((unsigned)ublocks, 1), dim3(256), 0, s, prec, item_emb, (int)n_items_plus1, history,
-                           hist_stride, (int)U, per, k, (float2*)nullptr, topk_ids, topk_scores);
+                           hist_stride, (int)U, per, k, (tkey*)nullptr, topk_ids, topk_scores);
         IISAN_LAUNCH_OK();
         return IISAN_OK;
     }
     hipLaunchKernelGGL(score_topk_kernel<false>, dim3((unsigned)ublocks, (unsigned)splits), dim3(256), 0, s, prec, item_emb, (int)n_items_plus1,
-                       history, hist_stride, (int)U, per, k, (float2*)ws, topk_ids, topk_scores);
+                       history, hist_stride, (int)U, per, k, (tkey*)ws, topk_ids, topk_scores);
     IISAN_LAUNCH_OK();
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)U), dim3(64), 0, s, (const float2*)ws, splits, (int)U, k, topk_ids, topk_scores);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)U), dim3(64), 0, s, (const tkey*)ws, splits, (int)U, k, topk_ids, topk_scores);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
