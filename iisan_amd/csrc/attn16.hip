@@ -11,8 +11,8 @@
 //     ONE query (lane&15), keys 16t + 4(lane>>4) + r — the softmax row reduction is a per-lane loop plus two
 //     xor-shuffles (16, 32), and the exponentiated registers are ALREADY in B-operand layout for the second
 //     product O^T = V^T · P^T (k-slot e of lane group g <-> key 32kb + 4g + e | 32kb + 16 + 4g + (e-4));
-//   * V is transposed into LDS while staging (V^T[d][key], row stride padded to 16*NT16+4 elements) so the A
-//     operand of the second product is two 8-byte LDS reads per fragment;
+//   * V is transposed into LDS while staging (V^T[d][slot], keys permuted inside groups of 32: see VT_LD) so the A
+//     operand of the second product is ONE 16-byte LDS read per fragment;
 //   * K rows are 128 bytes, 16-byte slots XOR-swizzled with (row&7): conflict-free ds_read_b128;
 //   * fp32 softmax statistics; masked keys (BERT attention_mask == 0) take the constant fp32-min score exactly like
 //     HF's additive mask, so an all-masked padding item attends uniformly; structural pad keys get -inf.
@@ -74,10 +74,13 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
     const int dbg = dbg_arg;
 #endif
     constexpr int SP = NT16 * 16;
-    // V^T row stride (elements), see VT_LD below; (history: 264 = 132 dwords was chosen for a half-wave (16 d-rows x 2 key
-    // groups) hit 32 distinct bank pairs; for short sequences any stride works (one bank row covers everything).
-    constexpr int VT_LD = SP > 208 ? 260 : (SP > 128 ? 212 : SP + 8);     // 106 dwords = 10 (mod 32): the 16 rows of a ds_read2_b64 lane group hit 16 distinct bank pairs (round 3: 260 = 130 dwords, same property; 264 gave 2-way conflicts, PMC).  212 >= 208 + 4 keeps K + V^T + the key limits at 54,592 bytes: three workgroups per CU; 14 tiles (S = 209..224) need a stride >= 224 + 4: 260 (with 212 the V^T rows of neighbouring head dims overlapped and the last one ran into the key limits)
-    static_assert(VT_LD >= SP + 4, "a V^T row holds SP keys and the 16-key tail read reaches SP - 16 + 12 + 4");
+    // V^T[d][slot] in LDS, keys PERMUTED inside every group of 32 so that the eight contraction values a lane needs for one P.V step — keys
+    // 32 kb + 4 g + (0..3) of score tile 2 kb and 32 kb + 16 + 4 g + (0..3) of tile 2 kb + 1 — are contiguous: key 16 t + 4 g' + r sits at slot
+    // 32 (t >> 1) + 8 g' + 4 (t & 1) + r, and a fragment is ONE ds_read_b128 (round 6; before: two 8-byte pieces 32 bytes apart, read as a
+    // ds_read2_b64 — 8 LDS cycles per wave-instruction instead of 4, MI355X_MICROARCH.md LDS table; the reads were a third of the kernel's LDS time).
+    // Row stride: the slots an odd tile count leaves half-filled count, + 16 elements: rows 16 (mod 32) elements apart put the 16 rows of a
+    // ds_read_b128 lane group on 16 distinct bank quads (208 -> 240: K + V^T + key limits = 58,176 B, two workgroups per CU as the registers allow).
+    constexpr int VT_LD = 32 * ((NT16 + 1) / 2) + 16;
     constexpr int MAXQB = (NT16 + 3) / 4;            // 16-query blocks per wave
     constexpr int KP = (SP + 31) / 32;                // K passes: 32 rows per pass (the last may be partial: NT16 odd)
     constexpr int VP = (SP / 4 + 31) / 32;            // V passes: 32 four-key groups per pass
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
                     V4 t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t[r] = vreg[p][r][e];
-                    if (!(dbg & 1)) *(V4*)(sVt + (c * 8 + e) * VT_LD + kg * 4) = t;
+                    if (!(dbg & 1)) *(V4*)(sVt + (c * 8 + e) * VT_LD + 32 * (kg >> 3) + 8 * (kg & 3) + 4 * ((kg >> 2) & 1)) = t;
                 }
             }
         }
@@ -260,15 +263,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
             {
                 auto vload = [&](int kb, V8 (&vf)[4]) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const E* vr = sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 4;
-                        const V4 lo = *(const V4*)vr, hi2 = *(const V4*)(vr + 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            vf[dt][e] = lo[e];
-                            vf[dt][4 + e] = hi2[e];
-                        }
-                    }
+                    for (int dt = 0; dt < 4; ++dt) vf[dt] = *(const V8*)(sVt + (dt * 16 + j) * VT_LD + kb * 32 + g * 8);
                 };
                 V8 vc[4];
                 vload(0, vc);
@@ -296,7 +291,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
                     for (int e = 0; e < 4; ++e) pt[e] = T::from_f32(sc[NT16 - 1][e]);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
-                        o[dt] = Mfma16k16<T>::run(*(const V4*)(sVt + (dt * 16 + j) * VT_LD + (SP - 16) + g * 4), pt, o[dt]);
+                        o[dt] = Mfma16k16<T>::run(*(const V4*)(sVt + (dt * 16 + j) * VT_LD + (NT16 / 2) * 32 + g * 8), pt, o[dt]);
                 }
             }
             // A lane holds 4 consecutive head dims (8 B) of its query per 16-dim tile; lanes 16 apart (g, g+1) hold the
