@@ -333,6 +333,10 @@ size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K);
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags);
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
 
+// amax of up to 16 tensors in one launch (split.hip): x row-major [rows, cols] with leading dimension ld; out = the caller's zeroed amax slot
+struct AmaxBatch { const float* x[16]; int64_t rows[16], cols[16], ld[16]; uint32_t* out[16]; };
+int launch_amax_batch(const AmaxBatch& b, int n, hipStream_t s);
+
 struct Gemm32Prob {
     const float* A; const float* B; const float* bias; const float* resid; const float* act_src; float* C;
     int64_t M; int32_t N; int64_t K;

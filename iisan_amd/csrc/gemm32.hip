@@ -805,8 +805,10 @@ __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int 
     const int ks = ks_launch < rb.ns[blockIdx.z] ? ks_launch : rb.ns[blockIdx.z];
     const float* P = rb.P[blockIdx.z];
     const int64_t stride = rb.stride[blockIdx.z], total = p.M * p.N;
-    if (rb.cs[blockIdx.z] && blockIdx.x == 0) {         // column sums of the A operand: M values per split, fixed order
-        for (int64_t m = threadIdx.x; m < p.M; m += blockDim.x) {
+    if (rb.cs[blockIdx.z]) {         // column sums of the A operand: M values per split, fixed order (y ascending)
+        // one value per thread over the first ceil(M / 256) workgroups.  (Until round 6 workgroup 0 walked all M values alone: at Versa's
+        // M = 8192 that is 32 dependent rounds of loads by one workgroup — 33.8 us for a launch whose other workgroups finish in 6.)
+        for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
             float v = 0.f;
             for (int y = 0; y < ks; ++y) v += P[(int64_t)y * stride + total + m];
             rb.cs[blockIdx.z][m] += v;

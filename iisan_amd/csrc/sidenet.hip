@@ -296,16 +296,43 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
 
 // the problems of one launch group: the large ones as split-operand GEMMs, the rest together on the f32 matrix cores
 int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStream_t s) {
-    Gemm32Prob rest[4];
-    int nr = 0;
+    Gemm32Prob rest[IISAN_MAX_SIDE], big[IISAN_MAX_SIDE];
+    int nr = 0, nb = 0;
+    IISAN_CHECK_SHAPE(n <= IISAN_MAX_SIDE, "gemm_group: %d problems", n);
     for (int i = 0; i < n; ++i) {
         if (b.x3 && gemm_x3_applicable(pr[i], flags)) {
             Gemm32Prob q = pr[i];
             if (b.x3z_left > 0) { q.x3_zeroed = b.x3z_next; b.x3z_next += X3Z_WORDS; --b.x3z_left; }
-            IISAN_TRY(launch_gemm_x3(q, flags, b.x3, b.x3_bytes, s));
+            big[nb++] = q;
         }
         else rest[nr++] = pr[i];
     }
+    // Round 6: the amax passes of every operand the group's split-operand products still need go out as ONE launch (they were one
+    // launch per operand and product: 5 - 16 us each, latency-bound).  An operand without a caller-owned slot uses the first / second
+    // word of the product's private zeroed block (what launch_gemm_x3 would have used itself); products without one keep their own pass.
+    if (nb > 1 || (nb == 1 && big[0].x3_zeroed)) {
+        AmaxBatch ab{};
+        int na = 0;
+        auto want = [&](const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, uint32_t* slot) {
+            for (int k = 0; k < na; ++k) if (ab.out[k] == slot) return;            // the same tensor twice in one group
+            if (na >= 16) return;
+            ab.x[na] = x; ab.rows[na] = trans ? K : op_rows; ab.cols[na] = trans ? op_rows : K; ab.ld[na] = ld; ab.out[na] = slot;
+            ++na;
+        };
+        for (int i = 0; i < nb; ++i) {
+            Gemm32Prob& q = big[i];
+            if (!q.x3_zeroed && !(q.amax_a && q.amax_b)) continue;
+            uint32_t* pa = q.amax_a ? q.amax_a : q.x3_zeroed;
+            uint32_t* pb = q.amax_b ? q.amax_b : q.x3_zeroed + 1;
+            const bool full = na + 2 > 16;
+            if (full) break;
+            if (!q.amax_a_ready) want(q.A, (flags & G32_TA) != 0, q.M, q.K, q.lda, pa);
+            if (!q.amax_b_ready) want(q.B, (flags & G32_TB) != 0, q.N, q.K, q.ldb, pb);
+            q.amax_a = pa; q.amax_b = pb; q.amax_a_ready = 1; q.amax_b_ready = 1;
+        }
+        IISAN_TRY(launch_amax_batch(ab, na, s));
+    }
+    for (int i = 0; i < nb; ++i) IISAN_TRY(launch_gemm_x3(big[i], flags, b.x3, b.x3_bytes, s));
     // A skinny long-K product (Versa's fc_bert: [1408, 8192] -> 64) must not share a launch with short-K ones: alone it takes the
     // split-K route through the executor's scratch (33 us); grouped, the launch has "enough" workgroups, nothing is split and its
     // 22 workgroups walk 128 K-tiles each while the rest of the chip idles (195 us per Versa step, profiles/r3a_versa_*).
@@ -320,7 +347,8 @@ int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStr
             } else ++i;
         }
     }
-    if (nr) IISAN_TRY(launch_gemm32(rest, nr, flags & ~G32_HINT_B_EXACT16, s));
+    for (int i = 0; i < nr; i += 4)          // (a launch takes four problems: Gemm32Batch)
+        IISAN_TRY(launch_gemm32(rest + i, nr - i < 4 ? nr - i : 4, flags & ~G32_HINT_B_EXACT16, s));
     return IISAN_OK;
 }
 
@@ -469,16 +497,21 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
     // the dim-align products skip the tap's amax pass (15 us each at Versa's [1408, 8192]), forward and weight gradient.
     const bool taps_preset = cfg->taps_exact16 && p.align && p.n[2] > 0;
     if (taps_preset) IISAN_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(b.amax + 9), 0x46000000, (size_t)p.n[2], s));
+    if (p.align && p.n[2] > 0) {
+        // dim-align the wider modality's taps (Code_Cached_Asym/model/model.py:404-411).  The products depend on taps and weights only, not on
+        // the chain: round 6 issues them as ONE group ahead of it (they used to sit in front of their steps, one amax launch per weight each)
+        Gemm32Prob pd[IISAN_MAX_SIDE];
+        const int zw = p.text_wide ? 1 : 0;
+        for (int i = 0; i < p.n[2]; ++i) {
+            const StepMap sm = step_map(p, p.diff_cv + p.diff_t + i);
+            pd[i] = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(i)), p.D[zw], c.W(p.dpw(i) + 1), b.DP[i], p.D[2], M, p.D[2], p.D[zw]);
+            pd[i].amax_a = b.amax + 9 + i;           // the tap's amax: read again by the weight-gradient product of this step
+            pd[i].amax_a_ready = taps_preset ? 1 : 0;
+        }
+        IISAN_TRY(gemm_group(pd, p.n[2], 0, b, s));
+    }
     for (int g = 0; g < nsteps; ++g) {
         const StepMap sm = step_map(p, g);
-        if (sm.mm_i >= 0 && p.align) {        // dim-align the wider modality's tap (Code_Cached_Asym/model/model.py:404-411)
-            const int zw = p.text_wide ? 1 : 0;
-            Gemm32Prob pd = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(sm.mm_i)), p.D[zw], c.W(p.dpw(sm.mm_i) + 1),
-                                 b.DP[sm.mm_i], p.D[2], M, p.D[2], p.D[zw]);
-            pd.amax_a = b.amax + 9 + sm.mm_i;        // the tap's amax: read again by the weight-gradient product of this step
-            pd.amax_a_ready = taps_preset ? 1 : 0;
-            IISAN_TRY(gemm_group(&pd, 1, 0, b, s));
-        }
         if (step_fusable(p, sm, M)) {         // fusion + down + activation + up of every active tower in one launch
             SanbTowerDesc td[3];
             for (int a = 0; a < sm.nact; ++a) {

@@ -27,16 +27,16 @@ struct SplitArgs {
     int32_t* lo_flag;      // out: set to 1 when any lo element is non-zero (pre-zeroed; plain stores of the same value)
 };
 
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
-                                                   uint32_t* amax_bits) {
+__device__ __forceinline__ void amax_body(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld, uint32_t* amax_bits,
+                                          int64_t block, int64_t nblocks) {
     // cols % 4 == 0 and 16-byte aligned rows are checked on the host.  ONE atomic per workgroup and at most 512
     // workgroups: same-address atomics serialise (the first version issued one per wave from 2048 workgroups — 8192
     // atomics on one word — and took 103 us for a 35 MB tensor, 10x its HBM time).
     __shared__ float red[4];
     const int64_t c4 = cols / 4, total = rows * c4;
     float m = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = nblocks * blockDim.x;
+    int64_t i = block * blockDim.x + threadIdx.x;
     // four loads in flight per thread (one per iteration left the pass latency-bound: 12.6 us for 35 MB)
     for (; i + 3 * stride < total; i += 4 * stride) {
         f4 v[4];
@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bit patterns
     }
+}
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                   uint32_t* amax_bits) {
+    amax_body(x, rows, cols, ld, amax_bits, blockIdx.x, gridDim.x);
+}
+
+// the amax of several tensors in ONE launch (blockIdx.y = tensor): the operands of a group of split-operand products — the three fc
+// layers of a direction, Versa's seven dim-align weights — paid a launch of 5 - 16 us each, latency-bound (a 33.5 MB weight at 2.1 TB/s)
+__global__ __launch_bounds__(256) void amax_batch_kernel(AmaxBatch b) {
+    const int z = blockIdx.y;
+    amax_body(b.x[z], b.rows[z], b.cols[z], b.ld[z], b.out[z], blockIdx.x, gridDim.x);
 }
 
 // s = 2^(13 - floor(log2 amax)): the largest element lands in [2^13, 2^14) (fp16 max 65504); amax == 0 or denormal -> s = 1
@@ -173,6 +185,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         *(f4*)(C + m * ldc + n) = v;
     }
 }
+
+}  // namespace
+
+int launch_amax_batch(const AmaxBatch& b, int n, hipStream_t s) {
+    if (n <= 0) return IISAN_OK;
+    int64_t blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        IISAN_CHECK_SHAPE(b.cols[i] % 4 == 0 && b.ld[i] % 4 == 0 && ((uintptr_t)b.x[i] & 15) == 0, "amax: source rows must be 16-byte aligned");
+        const int64_t w = ceil_div(b.rows[i] * (b.cols[i] / 4), 256 * 4);
+        if (w > blocks) blocks = w;
+    }
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(amax_batch_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, b);
+    IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+namespace {
 
 int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
                   int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s,
