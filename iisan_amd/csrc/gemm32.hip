@@ -1036,6 +1036,18 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
         if (probs[i].K < min_k) min_k = probs[i].K;
     }
     // K = 64 products with a wide N and a plain epilogue (bias / residual): gemm32_k64_kernel
+    if ((flags & ~G32_TB) == 0 && g_use_k64 && nprob > 1) {
+        // a group that mixes K = 64 products with others (Versa's fc backward: dO = dY Wf is [1408, 64] x [64 -> 1024 | 8192] for the two
+        // towers and [1408, 1024] x [1024 -> 1024] for the inter-modal one) used to go to the tiled kernel as a whole — one K-tile per
+        // workgroup for the K = 64 members: 68.6 us for 46 MB of output (round 6).  The K = 64 members get their own launch.
+        Gemm32Prob yes[4], no[4];
+        int ny = 0, nn = 0;
+        for (int i = 0; i < nprob; ++i) { if (k64_shape_ok(probs[i])) yes[ny++] = probs[i]; else no[nn++] = probs[i]; }
+        if (ny > 0 && nn > 0) {
+            IISAN_TRY(launch_gemm32_impl(yes, ny, flags, s));
+            return launch_gemm32_impl(no, nn, flags, s);
+        }
+    }
     if ((flags & ~G32_TB) == 0 && g_use_k64) {
         bool ok = true;
         int64_t maxM = 0;
@@ -1145,7 +1157,10 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
     // 16-byte stores of the partials and a reducer that adds them to C in a fixed order — faster, and the weight gradients
     // become bit-reproducible.  Falls back to atomics when the scratch buffer is missing or too small.
     int structural = flags & (G32_TA | G32_TB | G32_ACCUM);
-    if ((flags & G32_ACCUM) && g_scratch && g_accum_via_scratch && splitk >= 2) {
+    // (round 6: gemm32_dw_kernel also when ONE split is wanted — a group whose tiles already fill the chip, like Versa's fc weight
+    //  gradients (400 tiles), fell back to the tiled kernel: 22 K-tiles in a row per workgroup, 77 us; the raw partial costs one more pass
+    //  of the reducer over the output and is still the faster route)
+    if ((flags & G32_ACCUM) && g_scratch && g_accum_via_scratch && (splitk >= 2 || dw_ok)) {
         {   // only NON-EMPTY K ranges: the kernel gives split y the K-tiles [y, y+1) * ceil(ktiles / splits) and a split whose
             // range is empty writes nothing — its partial would be read uninitialised by the reducer
             const int64_t ktiles = ceil_div(min_k, (int64_t)TK), per = ceil_div(ktiles, (int64_t)splitk);
