@@ -303,3 +303,24 @@ def test_h256_head_major_addressing_bound_is_independent_of_which0():
     # the 16-bit row-major epilogues keep their own (leading-dimension) bound
     assert lib.iisan_gemm16_h256_applicable(0, 1_390_000, 768, 768, 0, 0, 0) == 1
     assert lib.iisan_gemm16_h256_applicable(0, 277376, 768, 64, 0, 0, 0) == 0                       # K / 64 < 2
+
+
+def test_tools_compile_and_name_only_declared_entry_points():
+    """a development tool that still iterated a table the ABI clean-up had removed died silently in every child process.  Every
+    script under tools/ must byte-compile, and every `iisan_*` entry point it names must be one the loader binds (`_lib.SIGNATURES` =
+    the symbols include/iisan_hip.h declares); attributes of `_lib` it touches must exist."""
+    import glob
+    import py_compile
+    import re
+    from iisan_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    retired = {"iisan_set_x3"}                       # named in prose (error messages / docstrings) only
+    for path in sorted(glob.glob(os.path.join(root, "tools", "*.py"))):
+        py_compile.compile(path, doraise=True)
+        src = open(path).read()
+        for name in set(re.findall(r"\biisan_[a-z0-9_]+\b", src)):
+            if name in ("iisan_amd", "iisan_hip", "iisan_oracle") or name in retired:
+                continue
+            assert name in _lib.SIGNATURES, f"{os.path.basename(path)} names {name}, which the library does not export"
+        for attr in set(re.findall(r"\b_lib\.([A-Za-z_]+)\b", src)):
+            assert hasattr(_lib, attr), f"{os.path.basename(path)} uses _lib.{attr}, which does not exist"
