@@ -55,6 +55,12 @@ int iisan_dev_register(const IisanDevKnob& k);
 #define IISAN_DEV_KNOB(NAME, VAR)                                                                                \
     static const int iisan_dev_reg_##NAME = iisan_dev_register(IisanDevKnob{                                     \
         #NAME, (int64_t)(VAR), [] { return (int64_t)(VAR); }, [](int64_t v) { VAR = (decltype(VAR))v; }})
+// ROUTE COUNTERS (round 6): "how often did this kernel family launch" — read through iisan_dev_get("count:<name>"), zeroed by iisan_dev_set(..., 0) /
+// iisan_dev_reset; never part of iisan_dev_state (def = INT64_MIN marks a counter).  tests/test_gpu_trainable.py pins the DEFAULT dispatch of the
+// bench shapes with them: a threshold that silently sends the headline to another kernel family fails a test.
+#define IISAN_DEV_COUNTER(NAME, VAR)                                                                             \
+    static const int iisan_dev_cnt_##NAME = iisan_dev_register(IisanDevKnob{                                     \
+        "count:" #NAME, INT64_MIN, [] { return (int64_t)(VAR); }, [](int64_t v) { VAR = (decltype(VAR))v; }})
 // ... with a side effect behind the store (SET is a statement using the new value `v`)
 #define IISAN_DEV_KNOB_FN(NAME, VAR, SET)                                                                        \
     static const int iisan_dev_reg_##NAME = iisan_dev_register(IisanDevKnob{                                     \

@@ -46,7 +46,7 @@ extern "C" int64_t iisan_dev_get(const char* name) {
 }
 
 extern "C" void iisan_dev_reset(void) {
-    for (const auto& k : knobs()) k.set(k.def);
+    for (const auto& k : knobs()) k.set(k.def == INT64_MIN ? 0 : k.def);      // (INT64_MIN: a route counter, common.h IISAN_DEV_COUNTER)
 }
 
 // "name=value,name=value" of every switch that is not at its library default ("" = the product routes); with all != 0 every
@@ -55,7 +55,8 @@ extern "C" size_t iisan_dev_state(char* buf, size_t cap, int32_t all) {
     std::string s;
     for (const auto& k : knobs()) {
         const int64_t v = k.get();
-        if (!all && v == k.def) continue;
+        if (k.def == INT64_MIN) { if (!all) continue; }          // a route counter is not a switch: only the full listing shows it
+        else if (!all && v == k.def) continue;
         if (!s.empty()) s += ',';
         s += k.name;
         s += '=';

@@ -259,6 +259,10 @@ static int g_auto_staggered = 1;
 // A/B of tools/gemm_var.py over three boxes: QKV +1..4 %, O +1 %, FC1 +-0, FC2 +3..4 %; bit-identical results), 0 = gemm16_s256.hip.
 // (round 5: the switch that sent the production shapes back to gemm16_s256.hip is retired; variant 3 still forces that kernel for the race screen)
 IISAN_DEV_KNOB(gemm16_variant, g_variant);
+static int64_t g_cnt_h256 = 0, g_cnt_s256 = 0, g_cnt_v1 = 0;      // launches of launch_gemm16 by kernel family
+IISAN_DEV_COUNTER(gemm16_h256, g_cnt_h256);
+IISAN_DEV_COUNTER(gemm16_s256, g_cnt_s256);
+IISAN_DEV_COUNTER(gemm16_v1, g_cnt_v1);
 // tile walk of gemm16_h256 (bench knob): c = -1 auto policy, 0 = row-major tile list, > 0 = panels of c column tiles walked down
 // sub-slabs of h row tiles (h <= 0: the XCD's whole slab)
 static int g_walk_c = -1, g_walk_h = 0;
@@ -295,6 +299,7 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
         const bool auto_panel = a.N / 256 >= 6 && ceil_div(a.M, 256) >= 128;
         b.walk_c = g_walk_c < 0 ? (auto_panel ? 3 : 0) : g_walk_c;
         b.walk_h = g_walk_c < 0 ? 16 : g_walk_h;
+        ++g_cnt_h256;
         rc = launch_gemm16_h256(dtype16, mode, b, s);
         if (timed) iisan_timing_post(s);
         return rc;
@@ -307,11 +312,12 @@ int launch_gemm16(int dtype16, int mode, const Gemm16Args& a, hipStream_t s) {
     if (big && (var == 3 || (var == 0 && g_auto_staggered)) && gemm16_s256_applicable(mode, a)) {
         Gemm16Args b = a;
         b.debug = g_variant >> 8;
+        ++g_cnt_s256;
         rc = launch_gemm16_s256(dtype16, mode, b, s);
     }
     // everything else — small shapes, the fp32 / residual epilogues (round 4 retired the lock-step 256x256 kernel gemm16_p256.hip: its
     // last product, the patch embedding, runs on gemm16_h256 with a 16-bit output) — on the 128x128 kernel
-    else rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s);
+    else { ++g_cnt_v1; rc = dtype16 == IISAN_BF16 ? launch_t<BF16>(mode, a, s) : launch_t<F16>(mode, a, s); }
     if (timed) iisan_timing_post(s);
     return rc;
 }

@@ -891,6 +891,10 @@ int launch_flags(const Gemm32Batch& b, dim3 grid, int tm, int epi, bool fast, bo
 
 // 1 (default): K = 64 products with a wide N and a plain epilogue take gemm32_k64_kernel; 0: the tiled kernel.  Test / bench knob.
 static int g_use_k64 = 1, g_use_dw = 1;
+static int64_t g_cnt_n64f = 0, g_cnt_k64 = 0, g_cnt_dw = 0;      // launches by kernel (route counters, common.h)
+IISAN_DEV_COUNTER(gemm32_n64f, g_cnt_n64f);
+IISAN_DEV_COUNTER(gemm32_k64, g_cnt_k64);
+IISAN_DEV_COUNTER(gemm32_dw, g_cnt_dw);
 IISAN_DEV_KNOB(gemm32_dw, g_use_dw);
 IISAN_DEV_KNOB(gemm32_k64, g_use_k64);
 
@@ -951,6 +955,7 @@ static int launch_gemm32_n64f_impl(const N64FDesc* d, int n, int gelu, hipStream
             off += ks * nb.p[i].pstride;
         }
     }
+    ++g_cnt_n64f;
     hipLaunchKernelGGL(gemm32_n64f_kernel, dim3((unsigned)rt, (unsigned)ks, (unsigned)n), dim3(256), 0, s, nb);
     IISAN_LAUNCH_OK();
     if (ks < 2) return IISAN_OK;
@@ -1019,6 +1024,7 @@ static int launch_gemm32_k64_gate_impl(const Gemm32Prob* probs, const K64Gate* g
     static OncePerDevice attr;
     if (attr.first())
         IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
+    ++g_cnt_k64;
     hipLaunchKernelGGL((gemm32_k64_kernel<true, true>), grid, dim3(256), lds, s, kb, nblk);
     IISAN_LAUNCH_OK();
     return IISAN_OK;
@@ -1081,6 +1087,7 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
                 IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
                 IISAN_HIP_OK(hipFuncSetAttribute((const void*)gemm32_k64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 68 * 4));
             }
+            ++g_cnt_k64;
             if (flags & G32_TB) hipLaunchKernelGGL(gemm32_k64_kernel<true>, grid, dim3(256), lds, s, kb, nblk);
             else hipLaunchKernelGGL(gemm32_k64_kernel<false>, grid, dim3(256), lds, s, kb, nblk);
             IISAN_LAUNCH_OK();
@@ -1197,6 +1204,7 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
     int rc;
     bool cs_folded = false;          // the A operand's column sums came out of the product kernel
     if (dw_ok && via_scratch && structural == (G32_TA | G32_TB)) {
+        ++g_cnt_dw;
         hipLaunchKernelGGL(gemm32_dw_kernel, grid, dim3(256), 0, s, b);
         IISAN_LAUNCH_OK();
         rc = IISAN_OK;

@@ -436,8 +436,11 @@ static int launch_sanb(const SanbTowerDesc* towers, int n, int64_t M, int gelu, 
     return IISAN_OK;
 }
 
-int launch_sanb_fwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) { return launch_sanb<false>(towers, n, M, gelu, s); }
-int launch_sanb_bwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) { return launch_sanb<true>(towers, n, M, gelu, s); }
+static int64_t g_cnt_sanb_fwd = 0, g_cnt_sanb_bwd = 0;       // fused one-launch SANB steps (route counters, common.h)
+IISAN_DEV_COUNTER(sanb_fused_fwd, g_cnt_sanb_fwd);
+IISAN_DEV_COUNTER(sanb_fused_bwd, g_cnt_sanb_bwd);
+int launch_sanb_fwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) { ++g_cnt_sanb_fwd; return launch_sanb<false>(towers, n, M, gelu, s); }
+int launch_sanb_bwd(const SanbTowerDesc* towers, int n, int64_t M, int gelu, hipStream_t s) { ++g_cnt_sanb_bwd; return launch_sanb<true>(towers, n, M, gelu, s); }
 
 int launch_sanb_transpose(const float* const* in, float* const* out, const int32_t* rows, const int32_t* cols, int n, hipStream_t s) {
     IISAN_CHECK_SHAPE(n >= 1 && n <= 6, "sanb_transpose: 1..6 matrices per launch");

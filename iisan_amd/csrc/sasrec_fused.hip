@@ -632,8 +632,12 @@ struct SasFusedPtrs {              // filled by sasrec.hip from its own carve
     float* Q[8]; float* K[8]; float* V[8]; float* P[8]; float* C[8]; float* Zattn[8]; float* X1[8]; float* Hf[8]; float* Zffn[8]; float* X2[8];
 };
 
+static int64_t g_cnt_sasrec_fused = 0;       // one-launch SASRec forward passes (route counter, common.h)
+IISAN_DEV_COUNTER(sasrec_fused_fwd, g_cnt_sasrec_fused);
+
 int launch_sasrec_fused_fwd(const iisan_sasrec_cfg* cfg, const float* x, const float* log_mask, int64_t B, const void* const* params,
                             float* y, const SasFusedPtrs& w, hipStream_t s) {
+    ++g_cnt_sasrec_fused;
     FusedFwdArgs a{};
     auto W = [&](int i) { return (const float*)params[i]; };
     a.x = x; a.log_mask = log_mask; a.pos = W(0); a.ln0g = W(1); a.ln0b = W(2);

@@ -303,7 +303,10 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags, void* ws, size_t w
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s) {
     return launch_gemm_x3_any(p, flags, ws, ws_bytes, s);
 }
+static int64_t g_cnt_x3 = 0;                  // split-operand products launched (route counter, common.h)
+IISAN_DEV_COUNTER(gemm_x3, g_cnt_x3);
 static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_t ws_bytes, hipStream_t s) {
+    ++g_cnt_x3;
     int flags = flags_in;
     IISAN_CHECK_SHAPE(x3_shape_ok(p, flags), "gemm_x3: unsupported problem (flags 0x%x, N %d)", flags, p.N);
     IISAN_CHECK_SHAPE(ws && ws_bytes >= gemm_x3_ws_bytes(p.M, p.N, p.K), "gemm_x3: workspace too small");

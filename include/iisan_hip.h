@@ -342,7 +342,9 @@ int32_t iisan_gemm16_h256_applicable(int32_t mode, int64_t M, int32_t N, int32_t
  * registered by the kernel files (csrc/common.h: IISAN_DEV_KNOB); iisan_dev_state(buf, cap, 1) lists them all.
  * set: 0 or IISAN_EBADSHAPE (unknown name).  get: the value, INT64_MIN for an unknown name.
  * state: writes "name=value,..." of every switch NOT at its library default (all != 0: every switch) and returns the
- * length needed; "" means the product routes are in force.  reset: every switch back to its default. */
+ * length needed; "" means the product routes are in force.  reset: every switch back to its default.
+ * Names of the form "count:<kernel family>" (round 6) are launch COUNTERS, not switches: get reads, set / reset zero them, state lists them only
+ * with all != 0.  tests/test_gpu_trainable.py pins the default dispatch of the bench shapes with them. */
 int32_t iisan_dev_set(const char* name, int64_t value);
 int64_t iisan_dev_get(const char* name);
 size_t iisan_dev_state(char* buf, size_t cap, int32_t all);

@@ -1363,3 +1363,66 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
         differ += int(not torch.equal(g0[k], g1[k]))
     if not (versa and route == "sanb"):      # Versa's towers have different widths: no fused step there (yet)
         assert differ > 0                    # the two routes really are different kernels
+
+
+def _route_counts():
+    names = ("gemm16_h256", "gemm16_s256", "gemm16_v1", "sanb_fused_fwd", "sanb_fused_bwd", "sasrec_fused_fwd", "gemm_x3", "gemm32_n64f",
+             "gemm32_k64", "gemm32_dw")
+    return {n: _lib.dev_get("count:" + n) for n in names}
+
+
+def _zero_route_counts():
+    for n in _route_counts():
+        _lib.dev_set("count:" + n, 0)
+
+
+def test_default_dispatch_takes_the_benchmarked_kernel_families_at_the_bench_shapes():
+    """the conftest fixture guards the development SWITCHES, not the dispatch THRESHOLDS — a changed size rule would send the
+    bench shapes to another kernel family silently (every family is parity-tested, so nothing would fail).  The library counts launches per
+    family (DEV section, `count:<name>`; csrc/common.h IISAN_DEV_COUNTER); with no switch touched:
+      * Uncached bs = 128 (the headline, every block on every token): all 97 encoder GEMM launches of a step on `gemm16_h256_kernel` (patch
+        embedding + 12 x 4 ViT products + 12 x 4 BERT products), none on the staggered or the 128 x 128 kernels; the seven SANB steps as fused
+        launches in both directions; SASRec as one launch; no split-operand product (the fc layers are 1.7 GFLOP each at 1,408 slots);
+      * Cached bs = 1024 (config 3): no fused SANB launch (11,264 slots >= 4,096), the fusion-fed down projection / K = 64 / weight-gradient
+        kernels of gemm32.hip instead (7 + 15 + 15 launches), nine split-operand products (three fc layers x forward, dX, dW)."""
+    from iisan_amd import tapstore
+    assert _lib.dev_state() == "", "this test is about the library's default routes"
+    # ---- the headline ----
+    vw, bw = weights.make_vit_weights(), weights.make_bert_weights()
+    b = synth.scientific_batch(bs=128, seed=12345).to("cuda")
+    args = helpers.make_args(drop_rate=0.0)
+    model = helpers.build_model(args, synth.SCI_ITEM_NUM, b.pop_prob.cpu(), vw, weights.VIT_BASE, bw, weights.BERT_BASE, cached=False)
+    model.train()
+    ids = b.ids.view(-1)
+    from iisan_amd import trainer
+    tr = trainer.FlatTrainer(model, args, 1)                            # the step bench.py times
+    with _lib.dev(full_blocks=1):
+        tr.step(ids, b.images, b.text, b.log_mask)                      # warm-up: weight packing, LayerNorm folding
+        torch.cuda.synchronize()
+        _zero_route_counts()
+        tr.step(ids, b.images, b.text, b.log_mask)
+        torch.cuda.synchronize()
+        c = _route_counts()
+    assert c["gemm16_h256"] == 97 and c["gemm16_s256"] == 0 and c["gemm16_v1"] == 0, str(c)
+    assert c["sanb_fused_fwd"] == 7 and c["sanb_fused_bwd"] == 7 and c["gemm32_n64f"] == 0, str(c)
+    assert c["sasrec_fused_fwd"] == 1 and c["gemm_x3"] == 0, str(c)
+    del model, tr
+    torch.cuda.empty_cache()
+    # ---- config 3 ----
+    n = 2000
+    bc = synth.scientific_batch(bs=1024, seed=43, item_num=n, res=2, words=2)
+    args = helpers.make_args(drop_rate=0.0)
+    model = helpers.build_model(args, n, bc.pop_prob, cached=True)
+    g = torch.Generator().manual_seed(5)
+    tabs = [torch.randn(n + 1, 7, 768, generator=g) * 0.25 for _ in range(2)]
+    model.tap_stores = tuple(tapstore.TapStore(t.cuda(), range(7), "cuda", "fp32") for t in tabs)
+    model.train()
+    tr = trainer.FlatTrainer(model, args, 1)
+    _zero_route_counts()
+    tr.step(bc.ids.view(-1).cuda(), None, None, bc.log_mask.cuda())
+    torch.cuda.synchronize()
+    c = _route_counts()
+    assert c["sanb_fused_fwd"] == 0 and c["sanb_fused_bwd"] == 0, str(c)
+    assert c["gemm32_n64f"] == 7 and c["gemm32_k64"] == 15 and c["gemm32_dw"] == 15, str(c)
+    assert c["gemm_x3"] == 9 and c["sasrec_fused_fwd"] == 1, str(c)
+    _zero_route_counts()
