@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
     typedef typename T::v8 V8;
     typedef typename T::v4 V4;
 #ifndef ATTN_DEBUG_BITS
-    // the ablation bits of tools/attn_time.py (dev switch attn_debug: 1 = no V^T write, 8 = no store, 16 = no K write) are compiled in
+    // the ablation bits of tools/attn_time.py (dev switch attn_debug: 1 = no V^T write, 8 = no store, 16 = no K write, 32 = no global loads, 64 = no
+    // query blocks) are compiled in
     // only with -DATTN_DEBUG_BITS; the product build folds the tests away
     (void)dbg_arg;
     constexpr int dbg = 0;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
 
     V8 kreg[KP], vreg[VP][4], qnext[MAXQB][2];
     auto load_head = [&](int h) {
+        if (dbg & 32) return;                   // ablation (debug builds): no global loads — compute, staging and stores on whatever the registers hold
         // head-major input [item][head][q|k|v][S][64]: three contiguous blocks per (item, head)
         const E* qb_ = qkv + ((int64_t)item * heads + h) * 3 * S * 64;
         const E* kb_ = qb_ + (int64_t)S * 64;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void attention16_kernel(const type
 #pragma unroll
         for (int i = 0; i < MAXQB; ++i) {
             const int qb = wave + 4 * i;
-            if (qb >= nqb) break;
+            if (qb >= nqb || (dbg & 64)) break;  // (ablation bit 64, debug builds: loads and staging alone)
             const int sq = qb * 16 + j;
 
             // S^T tiles: lane holds query j, keys 16t + 4g + r (raw dot products; the 1/8 scale is folded into exp2)
@@ -461,9 +463,9 @@ int launch_t(const void* qkv, const float* key_bias, void* ctx, int64_t items, i
     //  ViT layer for this one; it is no longer instantiated — round 5 route retirement)
 #define IISAN_ATTN_CASE(NT)                                                                                                       \
     if (key_bias == nullptr && S > 16 * (NT - 1))                                                                                 \
-        hipLaunchKernelGGL((attention16_kernel<T, NT, true, false>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31); \
+        hipLaunchKernelGGL((attention16_kernel<T, NT, true, false>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 127); \
     else                                                                                                                          \
-        hipLaunchKernelGGL((attention16_kernel<T, NT, true, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 31)
+        hipLaunchKernelGGL((attention16_kernel<T, NT, true, true>), grid, block, 0, s, (const E*)qkv, key_bias, (E*)ctx, S, heads, hpw, g_attn_dbg & 127)
     if (S <= 32) { IISAN_ATTN_CASE(2); }
     else if (S <= 64) { IISAN_ATTN_CASE(4); }
     else if (S <= 128) { IISAN_ATTN_CASE(8); }
