@@ -339,6 +339,18 @@ size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K);
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags);
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
 
+// split-operand GEMM on shared planes (gemm16_x3.hip): images A2 [Mpad, 2 kp] = [hi | lo], B2 [Npad, 2 kp]; out fp32 = (Ah Bh^T + Ah Bl^T + Al Bh^T) * inv_a * inv_b
+// (+ bias) (+ resid), or raw split-K partials at out + y * split_stride; lo_a / lo_b: device flags "the lo plane has a non-zero element"
+struct X3pArgs {
+    const _Float16* A2; const _Float16* B2;
+    int64_t M; int32_t N, kp;
+    const float* bias; const float* resid; float* out; int32_t ldo;
+    const float* inv_a; const float* inv_b;
+    const int32_t* lo_a; const int32_t* lo_b;
+    int64_t split_stride;
+};
+int launch_gemm16_x3p(const X3pArgs& a, int ksplit, hipStream_t s);
+
 // amax of up to 16 tensors in one launch (split.hip): x row-major [rows, cols] with leading dimension ld; out = the caller's zeroed amax slot
 struct AmaxBatch { const float* x[16]; int64_t rows[16], cols[16], ld[16]; uint32_t* out[16]; };
 int launch_amax_batch(const AmaxBatch& b, int n, hipStream_t s);

@@ -1,9 +1,10 @@
 // Split-operand GEMM for the big TRAINABLE products (fc_* 768x768 layers of the side network, Versa's dim-align
 // projections and their backward products): fp32 operands are split on the device into two fp16 planes,
 //     x * s = hi + lo,   hi = fp16(x*s),  lo = fp16(x*s - hi),   s = power of two chosen from the tensor's amax,
-// and   A·B^T  ~=  (Ah·Bh^T + Ah·Bl^T + Al·Bh^T) / (sA sB)   runs as ONE 16-bit MFMA GEMM with K' = 3K on operand images
-//     A' = [Ah | Ah | Al]   B' = [Bh | Bl | Bh]     (rows of 3*Kp 16-bit elements)
-// through the encoder GEMM kernel (gemm16.hip, fp32 accumulate).  hi and lo together carry 22 mantissa bits of every
+// and   A·B^T  ~=  (Ah·Bh^T + Ah·Bl^T + Al·Bh^T) / (sA sB)   runs as ONE 16-bit MFMA GEMM on operand images that hold each plane once,
+//     A2 = [Ah | Al]   B2 = [Bh | Bl]     (rows of 2*Kp 16-bit elements)
+// whose K-step stages the four tiles and runs the three tile products from them (gemm16_x3.hip; rounds 2 - 5: K' = 3K images [Ah|Ah|Al] x
+// [Bh|Bl|Bh] through the encoder GEMM kernel — a third more operand bytes for the same MFMAs).  hi and lo together carry 22 mantissa bits of every
 // element within 2^-16 of the tensor's amax (below that the error floor is 2^-38 of amax), the dropped lo·lo term is
 // 2^-22 relative: the product is within a few fp32 ulps of an fp32 FMA chain, at 1/3 of the 16-bit MFMA rate instead of
 // the f32-input matrix cores' 1/16 (MI355X_MICROARCH.md: 2.5 PF vs 157 TF).  The reference computes these Linear
@@ -18,9 +19,8 @@ namespace {
 struct SplitArgs {
     const float* x;        // source, row-major [rows, cols], leading dimension ld (floats)
     int64_t rows, cols, ld;
-    _Float16* out;         // [out_rows, 3*kp]
+    _Float16* out;         // [out_rows, 2*kp]: hi plane | lo plane
     int64_t out_rows, kp;  // padded operand rows / padded K (multiple of 64)
-    int32_t pattern;       // 0: [hi|hi|lo] (A operand)   1: [hi|lo|hi] (B operand)
     int32_t trans;         // 1: the operand is x^T (operand row = source column, K runs over source rows)
     uint32_t* amax_bits;   // in: bit pattern of max|x| (amax kernel)
     float* inv_scale;      // out: 1/s
@@ -133,10 +133,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
                 }
             }
         }
-        _Float16* o = a.out + r * 3 * a.kp + k;
+        _Float16* o = a.out + r * 2 * a.kp + k;
         *(h8*)o = hi;
-        *(h8*)(o + a.kp) = a.pattern ? lo : hi;
-        *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+        *(h8*)(o + a.kp) = lo;
         const u4 lb = __builtin_bit_cast(u4, lo);
         any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
@@ -178,10 +177,9 @@ __global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
             split1(T[kg + e][cc] * s, h, l);
             hi[e] = h; lo[e] = l;
         }
-        _Float16* o = a.out + orow * 3 * a.kp + r0 + kg;
+        _Float16* o = a.out + orow * 2 * a.kp + r0 + kg;
         *(h8*)o = hi;
-        *(h8*)(o + a.kp) = a.pattern ? lo : hi;
-        *(h8*)(o + 2 * a.kp) = a.pattern ? hi : lo;
+        *(h8*)(o + a.kp) = lo;
         const u4 lb = __builtin_bit_cast(u4, lo);
         any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
@@ -222,12 +220,12 @@ int launch_amax_batch(const AmaxBatch& b, int n, hipStream_t s) {
 
 namespace {
 
-int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, int pattern, _Float16* out,
+int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, _Float16* out,
                   int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s,
                   bool amax_ready = false) {
     SplitArgs a{};
     a.lo_flag = lo_flag;
-    a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.pattern = pattern; a.trans = trans ? 1 : 0;
+    a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.trans = trans ? 1 : 0;
     a.amax_bits = amax_bits; a.inv_scale = inv_scale;
     a.rows = trans ? K : op_rows;
     a.cols = trans ? op_rows : K;
@@ -267,7 +265,7 @@ static int x3_ksplit(int64_t mp, int64_t np, int64_t kp) {
 size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t kp = ceil_div(K, 64) * 64, mp = ceil_div(M, 128) * 128, np = ceil_div(N, 128) * 128;
     const int ks = x3_ksplit(mp, np, kp);
-    return align_up((size_t)mp * 3 * kp * 2, 256) + align_up((size_t)np * 3 * kp * 2, 256) + 256 +
+    return align_up((size_t)mp * 2 * kp * 2, 256) + align_up((size_t)np * 2 * kp * 2, 256) + 256 +
            (ks > 1 ? align_up((size_t)ks * M * N * 4, 256) : 0);
 }
 
@@ -313,38 +311,36 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_
     const int64_t kp = ceil_div(p.K, 64) * 64, mp = ceil_div(p.M, 128) * 128, np = ceil_div(p.N, 128) * 128;
     char* w = (char*)ws;
     _Float16* A16 = (_Float16*)w;
-    w += align_up((size_t)mp * 3 * kp * 2, 256);
+    w += align_up((size_t)mp * 2 * kp * 2, 256);
     _Float16* B16 = (_Float16*)w;
-    w += align_up((size_t)np * 3 * kp * 2, 256);
+    w += align_up((size_t)np * 2 * kp * 2, 256);
     char* z48 = p.x3_zeroed ? (char*)p.x3_zeroed : w;
     uint32_t* amax = (uint32_t*)z48;          // [0] A, [1] B
     float* inv = (float*)(z48 + 16);          // [0] A, [1] B
     int32_t* lo_flag = (int32_t*)(z48 + 32);  // [0] A, [1] B: any non-zero lo element
     if (!p.x3_zeroed) IISAN_HIP_OK(hipMemsetAsync(amax, 0, 48, s));
-    // K' = [hi·hi | hi·lo | lo·hi]: the plane that may be all zeros — the lo plane of an operand that is exact in fp16, like
-    // taps cached in fp16 — goes LAST, so the GEMM can drop the last third of K when the device-side flag says so
-    const bool b_last = (flags & G32_HINT_B_EXACT16) != 0;
+    // (G32_HINT_B_EXACT16 told the old route which operand's lo plane to put last in K' so that the GEMM could drop it; the plane-sharing
+    //  kernel reads both flags and skips whichever lo plane is all zeros — an operand that is exact in fp16, like taps cached in fp16)
     flags &= ~G32_HINT_B_EXACT16;
-    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, b_last ? 1 : 0, A16, mp, kp, p.amax_a ? p.amax_a : amax, inv, lo_flag, s,
+    IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, A16, mp, kp, p.amax_a ? p.amax_a : amax, inv, lo_flag, s,
                             p.amax_a && p.amax_a_ready));
     // B operand rows = N: stored [N,K] by default, [K,N] under G32_TB (then the operand is the source transposed)
-    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, b_last ? 0 : 1, B16, np, kp, p.amax_b ? p.amax_b : amax + 1, inv + 1, lo_flag + 1, s,
+    IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, B16, np, kp, p.amax_b ? p.amax_b : amax + 1, inv + 1, lo_flag + 1, s,
                             p.amax_b && p.amax_b_ready));
-    Gemm16Args g{};
-    g.A = A16; g.W = B16; g.bias = p.bias; g.out = p.C; g.resid = p.resid;
-    g.M = p.M; g.N = p.N; g.K = (int32_t)(3 * kp); g.lda = g.ldw = (int32_t)(3 * kp); g.ldo = p.ldc;
-    g.inv_a = inv; g.inv_b = inv + 1; g.atomic = 0;
-    g.skip_last_third = lo_flag + (b_last ? 1 : 0);
+    X3pArgs g{};
+    g.A2 = A16; g.B2 = B16; g.M = p.M; g.N = p.N; g.kp = (int32_t)kp;
+    g.bias = p.bias; g.resid = p.resid; g.out = p.C; g.ldo = p.ldc;
+    g.inv_a = inv; g.inv_b = inv + 1; g.lo_a = lo_flag; g.lo_b = lo_flag + 1;
     const bool accum = (flags & G32_ACCUM) != 0;
     const int ks = x3_ksplit(mp, np, kp);
     if (ks == 1) {
         // "+=": the previous value of C is the residual (read-modify-write by the one lane that owns the element)
         if (accum) { IISAN_CHECK_SHAPE(!p.resid, "gemm_x3: accumulate and residual together"); g.resid = p.C; }
-        return launch_gemm16_f32(g, 1, s);
+        return launch_gemm16_x3p(g, 1, s);
     }
     float* P = (float*)(w + 256);
     g.out = P; g.ldo = p.N; g.bias = nullptr; g.resid = nullptr; g.split_stride = p.M * (int64_t)p.N;
-    IISAN_TRY(launch_gemm16_f32(g, ks, s));
+    IISAN_TRY(launch_gemm16_x3p(g, ks, s));
     int64_t blocks = ceil_div(p.M * (p.N / 4), 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P, ks, g.split_stride, p.bias,
