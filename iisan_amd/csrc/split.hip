@@ -252,14 +252,23 @@ int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_
 
 int launch_gemm16_f32(const Gemm16Args& a, int ksplit, hipStream_t s);      // gemm16.hip
 
-// K-splits of a product: as many as it takes to put ~1.5 workgroups on every CU, at least 16 K-steps each, at most 8.
-// Partial products go to the workspace and a small reducer adds them (fp32 atomics run at ~20 G/s chip-wide: a split-K
-// epilogue on them took 430 us for 8 M outputs, tools/g16f32_time.py).
+// K-splits of a product.  Partial products go to the workspace and a small reducer adds them (fp32 atomics run at ~20 G/s chip-wide: a
+// split-K epilogue on them took 430 us for 8 M outputs, tools/g16f32_time.py).  Round 6: chosen by a cost estimate instead of "double until 384
+// workgroups" — the chip holds 2 x CUs workgroups of gemm16_x3p_kernel at a time, a split count that spills a few workgroups into another round
+// pays a whole round for them (Versa's dim-align product: 88 tiles x 8 splits = 704 workgroups on 512 slots, two rounds of 32 K-steps; five
+// splits = 440 workgroups, ONE round of 52), and every split costs a pass over its partial (written and read back: ~8 bytes per output).
+//   cost(ks) = ceil(tiles ks / slots) x (steps / ks + 4) K-step times (~1 us)  +  [ks > 1] ks x (8 M N bytes at ~5 TB/s)
 static int x3_ksplit(int64_t mp, int64_t np, int64_t kp) {
-    const int64_t tiles = (mp / 128) * (np / 128), nk = 3 * kp / 64;
-    int ks = 1;
-    while (tiles * ks < 384 && ks < 8 && nk / (ks * 2) >= 16) ks *= 2;
-    return ks;
+    const int64_t tiles = (mp / 128) * (np / 128), steps = kp / 32, slots = (int64_t)2 * iisan_cu_count();
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= 8; ++ks) {
+        if (ks > 1 && steps / ks < 12) break;
+        const double rounds = (double)ceil_div(tiles * ks, slots);
+        const double cost = rounds * ((double)steps / ks + 4.0) + (ks > 1 ? ks * (8.0 * (double)mp * (double)np / 5e6) : 0.0);
+        if (cost < best_cost * 0.97) { best_cost = cost; best = ks; }        // (ties and near-ties: the fewer splits)
+    }
+    return best;
 }
 
 size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K) {
