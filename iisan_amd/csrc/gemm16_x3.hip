@@ -17,13 +17,19 @@
 
 namespace {
 
-constexpr int XBM = 128, XBN = 128, XBK = 32;
-constexpr int XTILE = XBM * XBK * 2;          // 8 KiB
-constexpr int XSTAGE = 4 * XTILE;             // Ah | Al | Bh | Bl
+constexpr int XBM = 128, XBK = 32;
+constexpr int XTILE = XBM * XBK * 2;          // 8 KiB: an A-operand tile (128 rows x 64 B)
 
 __device__ __forceinline__ int nperm_x(int q) { return (q & ~31) + 8 * ((q & 15) >> 2) + 4 * ((q >> 4) & 1) + (q & 3); }
 
+// NB: 32-column groups per wave — 2: 128 x 128 tiles; 3: 128 x 192 tiles (round 6, second step: the chip holds 2 x CUs = 512 workgroups of this
+// kernel, and the Cached fc products are 88 x 6 = 528 tiles of 128 x 128 — a full round and one of 16 workgroups; as 88 x 4 = 352 tiles of
+// 128 x 192 they are ONE round)
+template <int NB>
 __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
+    constexpr int XBN = 64 * NB;                       // 128 / 192 columns
+    constexpr int WTILE = XBN * XBK * 2;               // 8 / 12 KiB
+    constexpr int XSTAGE = 2 * XTILE + 2 * WTILE;      // Ah | Al | Bh | Bl: 32 / 40 KiB
     __shared__ __attribute__((aligned(16))) char smem[2 * XSTAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,40 +45,39 @@ __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
     const char* Bg = (const char*)p.B2 + (int64_t)n0 * ld;
     // staging: wave w brings pieces 2w, 2w+1 (16 rows x 64 B each) of every tile; lane -> row-in-piece lane >> 2, physical slot lane & 3
     const int prow = lane >> 2, slog = (lane & 3) ^ ((-(prow >> 2)) & 3);
-    int64_t a_off[2], b_off[2];
+    int64_t a_off[2], b_off[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = (2 * wave + j) * 16 + prow;
-        a_off[j] = (int64_t)q * ld + slog * 16;
-        b_off[j] = (int64_t)nperm_x(q) * ld + slog * 16;
-    }
+    for (int j = 0; j < 2; ++j) a_off[j] = (int64_t)((2 * wave + j) * 16 + prow) * ld + slog * 16;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b_off[j] = (int64_t)nperm_x((NB * wave + j) * 16 + prow) * ld + slog * 16;
     const int64_t plane = (int64_t)p.kp * 2;                             // byte offset of the lo plane inside a row
     auto stage = [&](int kt, int buf) {
-        char* s = smem + buf * XSTAGE + (2 * wave) * 1024;
+        char* sa = smem + buf * XSTAGE + (2 * wave) * 1024;
+        char* sb = smem + buf * XSTAGE + 2 * XTILE + (NB * wave) * 1024;
         const int64_t kb = (int64_t)kt * (XBK * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(Ag + a_off[j] + kb, s + j * 1024);
+        for (int j = 0; j < 2; ++j) glds16(Ag + a_off[j] + kb, sa + j * 1024);
         if (a_lo) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(Ag + a_off[j] + kb + plane, s + XTILE + j * 1024);
+            for (int j = 0; j < 2; ++j) glds16(Ag + a_off[j] + kb + plane, sa + XTILE + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(Bg + b_off[j] + kb, s + 2 * XTILE + j * 1024);
+        for (int j = 0; j < NB; ++j) glds16(Bg + b_off[j] + kb, sb + j * 1024);
         if (b_lo) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(Bg + b_off[j] + kb + plane, s + 3 * XTILE + j * 1024);
+            for (int j = 0; j < NB; ++j) glds16(Bg + b_off[j] + kb + plane, sb + WTILE + j * 1024);
         }
     };
-    f4 acc[4][2][2];
+    f4 acc[4][NB][2];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int a = 0; a < 2; ++a) acc[b][nb][a] = (f4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fg = lane >> 4;
     const int foff = frow * 64 + ((fg ^ ((-(frow >> 2)) & 3)) << 4);
-    const int xoff = (wave_m * 64) * 64 + foff, woff = (wave_n * 64) * 64 + foff;
+    const int xoff = (wave_m * 64) * 64 + foff, woff = (wave_n * 32 * NB) * 64 + foff;
 
     int nk = p.kp / XBK, k_first = 0;
     {
@@ -92,23 +97,23 @@ __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
             const int cur = kt & 1;
             if (kt + 1 < nk) stage(k_first + kt + 1, cur ^ 1);
             const char* s = smem + cur * XSTAGE;
-            h8 xh[4], xl[4], wh[2][2], wl[2][2];
+            h8 xh[4], xl[4], wh[NB][2], wl[NB][2];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 xh[b] = *(const h8*)(s + xoff + b * 1024);
                 if (AL) xl[b] = *(const h8*)(s + XTILE + xoff + b * 1024);
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     wh[nb][a] = *(const h8*)(s + 2 * XTILE + woff + (nb * 2 + a) * 1024);
-                    if (BL) wl[nb][a] = *(const h8*)(s + 3 * XTILE + woff + (nb * 2 + a) * 1024);
+                    if (BL) wl[nb][a] = *(const h8*)(s + 2 * XTILE + WTILE + woff + (nb * 2 + a) * 1024);
                 }
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         acc[b][nb][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb][a], xh[b], acc[b][nb][a], 0, 0, 0);
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
         const int64_t m = m0 + wave_m * 64 + b * 16 + frow;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int n = n0 + wave_n * 64 + nb * 32 + 8 * fg;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + wave_n * 32 * NB + nb * 32 + 8 * fg;
             if (n + 8 > p.N) continue;                 // N % 8 == 0: a lane's 8 columns are all in or all out
             float v[8];
 #pragma unroll
@@ -162,12 +167,27 @@ __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
 
 }  // namespace
 
+// tile width of a product: 192 columns where that turns a partly filled last round into none (x3p_tile_n, shared with the K-split choice of split.hip)
+int x3p_tile_n(int64_t M, int64_t N) {
+    const int64_t slots = (int64_t)2 * iisan_cu_count(), rows = ceil_div(M, XBM);
+    const int64_t t128 = rows * ceil_div(N, 128), t192 = rows * ceil_div(N, 192);
+    if (N % 192 != 0) return 128;                      // (whole tiles only: the W image is padded to 128-row multiples)
+    // rounds of equal-length workgroups, a 192-wide tile taking 1.5x the time of a 128-wide one
+    const double c128 = (double)ceil_div(t128, slots), c192 = 1.5 * (double)ceil_div(t192, slots);
+    return c192 < c128 ? 192 : 128;
+}
+
 int launch_gemm16_x3p(const X3pArgs& a, int ksplit, hipStream_t s) {
     IISAN_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.kp > 0 && a.kp % 64 == 0 && a.N % 8 == 0 && a.ldo % 4 == 0, "gemm16_x3p: bad shape");
     IISAN_CHECK_SHAPE(ksplit >= 1 && (ksplit == 1 || a.split_stride > 0), "gemm16_x3p: split-K needs a partial-product buffer");
-    const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(a.N, XBN);
+    const int bn = x3p_tile_n(a.M, a.N);
+    const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(a.N, bn);
     IISAN_CHECK_SHAPE(tiles < (1ll << 31), "gemm16_x3p: grid too large");
-    hipLaunchKernelGGL(gemm16_x3p_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, s, a);
+    if (bn == 192) {
+        hipLaunchKernelGGL(gemm16_x3p_kernel<3>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(gemm16_x3p_kernel<2>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, s, a);
+    }
     IISAN_LAUNCH_OK();
     return IISAN_OK;
 }
