@@ -264,7 +264,7 @@ static int x3_ksplit(int64_t mp, int64_t np, int64_t kp) {
     const int64_t tiles = (mp / 128) * ceil_div(np, bn), steps = kp / 32 * bn / 128, slots = (int64_t)2 * iisan_cu_count();
     int best = 1;
     double best_cost = 1e30;
-    for (int ks = 1; ks <= 8; ++ks) {
+    for (int ks = 1; ks <= 16; ++ks) {
         if (ks > 1 && steps / ks < 12) break;
         const double rounds = (double)ceil_div(tiles * ks, slots);
         const double cost = rounds * ((double)steps / ks + 4.0) + (ks > 1 ? ks * (8.0 * (double)mp * (double)np / 5e6) : 0.0);
