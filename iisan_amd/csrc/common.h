@@ -338,6 +338,10 @@ struct Gemm32Prob;
 size_t gemm_x3_ws_bytes(int64_t M, int64_t N, int64_t K);
 bool gemm_x3_applicable(const Gemm32Prob& p, int flags);
 int launch_gemm_x3(const Gemm32Prob& p, int flags, void* ws, size_t ws_bytes, hipStream_t s);
+// a group of products with the same flags: one launch for all operand images, one for all split-K sums (split.hip)
+size_t gemm_x3_group_ws_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int n);
+int launch_gemm_x3_group(const Gemm32Prob* probs, int n, int flags, void* ws, size_t ws_bytes, hipStream_t s);
+int gemm_x3_group_max();          // products per group (dev knob x3_group)
 
 // split-operand GEMM on shared planes (gemm16_x3.hip): images A2 [Mpad, 2 kp] = [hi | lo], B2 [Npad, 2 kp]; out fp32 = (Ah Bh^T + Ah Bl^T + Al Bh^T) * inv_a * inv_b
 // (+ bias) (+ resid), or raw split-K partials at out + y * split_stride; lo_a / lo_b: device flags "the lo plane has a non-zero element"
@@ -366,6 +370,9 @@ struct Gemm32Prob {
     // and weight-gradient products, a weight by forward and dX) then pays its amax pass once.  null = private slot, computed here.
     uint32_t* amax_a; uint32_t* amax_b;
     int32_t amax_a_ready, amax_b_ready;
+    // gemm_x3 only: the operand is exact in fp16 at scale 1 AND its amax slot is preset and ready (taps cached in fp16, cfg->taps_exact16): its lo
+    // plane is not written (it would be all zeros; the product skips a plane whose flag stays 0)
+    int32_t exact16_a, exact16_b;
     uint32_t* x3_zeroed;   // gemm_x3 only: 12 words the caller has zeroed for this product alone (private amax, 1/scale, lo flags); null = zeroed here
     // weight-gradient products (G32_TA | G32_TB | G32_ACCUM, A stored [K, M]): colsum_a[m] += sum_k A[k][m] — the bias gradient that
     // belongs to the same dY.  gemm32_dw_kernel sums the A tiles it stages anyway (round 3 re-read dY in a colsum launch of its

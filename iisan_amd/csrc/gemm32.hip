@@ -32,8 +32,9 @@ __host__ __device__ constexpr int ldt(int rows) { return rows == 16 ? 48 : rows 
 __host__ __device__ constexpr int smem_floats(int rows) { return rows * LD > TK * ldt(rows) ? rows * LD : TK * ldt(rows); }
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+constexpr int G32_MAXP = 6;          // problems per launch (round 6: the two weight-gradient products of a SANB step x three towers share one)
 struct Gemm32Batch {
-    Gemm32Prob p[4];
+    Gemm32Prob p[G32_MAXP];
 };
 
 // A 64 x 64 operand tile travels as 4 x float4 per thread.  Source stored [rows, K] (default): thread -> row
@@ -796,10 +797,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch b, int rows_per
     if (rl == 0 && n < b.N[z] && r0 < b.M[z]) atomicAdd(b.out[z] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
-// C = epilogue(sum_y P[y] + bias) (+ resid): the split-K partial products of up to 4 problems, fixed summation order
+// C = epilogue(sum_y P[y] + bias) (+ resid): the split-K partial products of up to G32_MAXP problems, fixed summation order
 // ns[z] = the K-splits of problem z that own a non-empty K range: only those wrote a partial (a shorter K than its launch
 // mates' leaves the rest of the scratch slots untouched — they are never read, so the scratch needs no zeroing)
-struct ReduceBatch { Gemm32Prob p[4]; const float* P[4]; int64_t stride[4]; int32_t ns[4]; float* cs[4]; };     // cs: colsum_a of problem z (its partials follow the C partial of every split)
+struct ReduceBatch { Gemm32Prob p[G32_MAXP]; const float* P[G32_MAXP]; int64_t stride[G32_MAXP]; int32_t ns[G32_MAXP]; float* cs[G32_MAXP]; };     // cs: colsum_a of problem z (its partials follow the C partial of every split)
 __global__ __launch_bounds__(256) void gemm32_reduce_kernel(ReduceBatch rb, int ks_launch, int epi) {
     const Gemm32Prob& p = rb.p[blockIdx.z];
     const int ks = ks_launch < rb.ns[blockIdx.z] ? ks_launch : rb.ns[blockIdx.z];
@@ -896,6 +897,8 @@ IISAN_DEV_COUNTER(gemm32_n64f, g_cnt_n64f);
 IISAN_DEV_COUNTER(gemm32_k64, g_cnt_k64);
 IISAN_DEV_COUNTER(gemm32_dw, g_cnt_dw);
 IISAN_DEV_KNOB(gemm32_dw, g_use_dw);
+static int g_dw_splits = 0;              // > 0: the split count of every gemm32_dw_kernel launch (sweeps)
+IISAN_DEV_KNOB(gemm32_dw_splits, g_dw_splits);
 IISAN_DEV_KNOB(gemm32_k64, g_use_k64);
 
 void gemm32_set_scratch(float* ws, size_t floats) { g_scratch = ws; g_scratch_floats = floats; }
@@ -1033,7 +1036,7 @@ static int launch_gemm32_k64_gate_impl(const Gemm32Prob* probs, const K64Gate* g
 int launch_colsum(const float* const* X, float* const* out, const int64_t* M, const int32_t* N, const int32_t* ld,
                   int nprob, hipStream_t s);
 static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
-    IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= 4, "gemm32: 1..4 problems per launch (got %d)", nprob);
+    IISAN_CHECK_SHAPE(nprob >= 1 && nprob <= G32_MAXP, "gemm32: 1..%d problems per launch (got %d)", G32_MAXP, nprob);
     Gemm32Batch b{};
     int64_t min_k = INT64_MAX;
     for (int i = 0; i < nprob; ++i) {
@@ -1046,7 +1049,7 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
         // a group that mixes K = 64 products with others (Versa's fc backward: dO = dY Wf is [1408, 64] x [64 -> 1024 | 8192] for the two
         // towers and [1408, 1024] x [1024 -> 1024] for the inter-modal one) used to go to the tiled kernel as a whole — one K-tile per
         // workgroup for the K = 64 members: 68.6 us for 46 MB of output (round 6).  The K = 64 members get their own launch.
-        Gemm32Prob yes[4], no[4];
+        Gemm32Prob yes[G32_MAXP], no[G32_MAXP];
         int ny = 0, nn = 0;
         for (int i = 0; i < nprob; ++i) { if (k64_shape_ok(probs[i])) yes[ny++] = probs[i]; else no[nn++] = probs[i]; }
         if (ny > 0 && nn > 0) {
@@ -1054,7 +1057,7 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
             return launch_gemm32_impl(no, nn, flags, s);
         }
     }
-    if ((flags & ~G32_TB) == 0 && g_use_k64) {
+    if ((flags & ~G32_TB) == 0 && g_use_k64 && nprob <= 4) {      // (K64Batch holds four)
         bool ok = true;
         int64_t maxM = 0;
         int maxnb = 0;
@@ -1130,6 +1133,12 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
             for (int i = 0; i < nprob; ++i) sum_tiles += (probs[i].M >> 6) * (probs[i].N >> 6);
             const int cus = iisan_cu_count();
             want = ((int64_t)cus + sum_tiles / 2) / sum_tiles;
+            // more than three problems = both weight gradients of a SANB step in one launch (round 6): TWO workgroups per CU (nearest count) —
+            // same-box sweeps: Cached (72 tiles, 176 K-tiles) 7 splits = 504 workgroups 4.78 - 4.81 ms per step, 6 4.86, 14 4.88 - 4.90,
+            // 3 4.91, 5 / 10 4.94 - 4.96, 4 = 288 (what the one-per-CU rule picks: a second, nearly empty round) 5.07; the two launches
+            // before 4.93 - 4.94.  Versa (320 tiles, 22 K-tiles) 2 splits 4.30 - 4.31 ms, 1 4.36 - 4.41, 3 4.38 - 4.39.
+            if (nprob > 3) want = ((int64_t)2 * cus + sum_tiles / 2) / sum_tiles;
+            if (g_dw_splits > 0 && nprob > 3) want = g_dw_splits;          // (sweeps of the merged SANB launches)
         }
         const int64_t maxs = ceil_div(min_k, 2 * TK);
         splitk = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
@@ -1224,11 +1233,11 @@ static int launch_gemm32_impl(const Gemm32Prob* probs, int nprob, int flags, hip
         default: iisan_set_error("gemm32: bad flags 0x%x", flags); return IISAN_EBADSHAPE;
     }
     if (rc == IISAN_OK && !cs_folded && (flags & G32_TA)) {          // every other route: the column sums as a launch of their own
-        const float* X[4]; float* O[4]; int64_t Ms[4]; int32_t Ns[4], lds[4];
+        const float* X[G32_MAXP]; float* O[G32_MAXP]; int64_t Ms[G32_MAXP]; int32_t Ns[G32_MAXP], lds[G32_MAXP];
         int n = 0;
         for (int i = 0; i < nprob; ++i)
             if (probs[i].colsum_a) { X[n] = probs[i].A; O[n] = probs[i].colsum_a; Ms[n] = probs[i].K; Ns[n] = (int32_t)probs[i].M; lds[n] = probs[i].lda; ++n; }
-        if (n) IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, n, s));
+        for (int i = 0; i < n; i += 4) IISAN_TRY(launch_colsum(X + i, O + i, Ms + i, Ns + i, lds + i, n - i < 4 ? n - i : 4, s));
     }
     if (rc != IISAN_OK || !via_scratch) return rc;
     ReduceBatch rb{};
@@ -1268,7 +1277,7 @@ struct TimedG32 {
 };
 int launch_gemm32(const Gemm32Prob* probs, int nprob, int flags, hipStream_t s) {
     double fl = 0, by = 0;
-    for (int i = 0; i < nprob && i < 4; ++i) {
+    for (int i = 0; i < nprob && i < G32_MAXP; ++i) {
         fl += 2.0 * (double)probs[i].M * probs[i].N * (double)probs[i].K;
         by += 4.0 * ((double)probs[i].M * probs[i].K + (double)probs[i].N * probs[i].K + (double)probs[i].M * probs[i].N);
     }

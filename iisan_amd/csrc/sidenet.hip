@@ -200,7 +200,7 @@ struct SideBufs {
     float* dO[3];                    // backward scratch [M, D_z]
     float* dY[3];                    // [M, H_z]
     float* dU[3];                    // [M, down]
-    float* dDP;                      // [M, d]
+    float* dDP[IISAN_MAX_SIDE];      // [M, d]: gradient wrt the dim-aligned tap of every aligned step (kept: their weight-gradient products run as one group after the chain)
     void* x3; size_t x3_bytes;       // scratch of the split-operand GEMM (operand images + scales), null = not used
     float* WT[3][2];                 // backward of the fused SANB step: fc_down^T [D, 64] and fc_up^T [64, D] of the current step
     float* skws; size_t skws_floats; // split-K scratch of the skinny long-K products (gemm32_set_scratch)
@@ -226,6 +226,7 @@ int g_use_x3 = 1;
 // 0: never.  Test / bench knob.
 constexpr int64_t SANB_FUSED_MAX_ROWS = 4096;
 int g_use_sanb = 1;
+int g_dw_merge = 1;                // 1 (default): dWu and dWd of a SANB step in one launch; 0: two (A/B knob)
 
 // what decides which products take the split-operand route: the on/off knob and the FLOP threshold, as one comparable word
 uint64_t x3_route_word() {
@@ -237,21 +238,34 @@ uint64_t x3_route_word() {
 
 size_t x3_need(const Plan& p, int64_t M) {
     if (!g_use_x3) return 0;
+    // the products of a launch group build their operand images together (split.hip: launch_gemm_x3_group): the workspace holds a whole group
     size_t need = 0;
+    int64_t gm[IISAN_MAX_SIDE], gn[IISAN_MAX_SIDE], gk[IISAN_MAX_SIDE];
+    int ng = 0;
     auto consider = [&](int64_t m, int64_t n, int64_t k) {
         Gemm32Prob q{};
         q.M = m; q.N = (int32_t)n; q.K = k; q.lda = q.ldb = q.ldc = q.ldr = 4;
-        if (gemm_x3_applicable(q, 0)) { const size_t b = gemm_x3_ws_bytes(m, n, k); if (b > need) need = b; }
+        if (gemm_x3_applicable(q, 0) && ng < IISAN_MAX_SIDE) { gm[ng] = m; gn[ng] = n; gk[ng] = k; ++ng; }
     };
-    for (int z = 0; z < 3; ++z) {
-        consider(M, p.H[z], p.D[z]);      // Y = O Wf^T
-        consider(M, p.D[z], p.H[z]);      // dO = dY Wf
-        consider(p.H[z], p.D[z], M);      // dWf += dY^T O
-    }
+    auto close_group = [&]() {
+        for (int i = 0; i < ng; i += 8) {
+            const size_t b = gemm_x3_group_ws_bytes(gm + i, gn + i, gk + i, ng - i < 8 ? ng - i : 8);
+            if (b > need) need = b;
+        }
+        ng = 0;
+    };
+    for (int z = 0; z < 3; ++z) consider(M, p.H[z], p.D[z]);      // Y = O Wf^T
+    close_group();
+    for (int z = 0; z < 3; ++z) consider(M, p.D[z], p.H[z]);      // dO = dY Wf
+    close_group();
+    for (int z = 0; z < 3; ++z) consider(p.H[z], p.D[z], M);      // dWf += dY^T O
+    close_group();
     if (p.align) {
         const int dw = p.text_wide ? p.D[1] : p.D[0];
-        consider(M, p.D[2], dw);          // DP = tap Pd^T
-        consider(p.D[2], dw, M);          // dPd += dDP^T tap
+        for (int i = 0; i < p.n[2]; ++i) consider(M, p.D[2], dw);          // DP = tap Pd^T
+        close_group();
+        for (int i = 0; i < p.n[2]; ++i) consider(p.D[2], dw, M);          // dPd += dDP^T tap
+        close_group();
     }
     return need;
 }
@@ -271,7 +285,7 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
         b.dY[z] = c.take<float>((size_t)M * p.H[z]);
         b.dU[z] = c.take<float>((size_t)M * p.r);
     }
-    b.dDP = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
+    for (int i = 0; i < p.n[2]; ++i) b.dDP[i] = p.align ? c.take<float>((size_t)M * p.D[2]) : nullptr;
     for (int z = 0; z < 3; ++z) {
         b.WT[z][0] = c.take<float>((size_t)p.D[z] * p.r);
         b.WT[z][1] = c.take<float>((size_t)p.D[z] * p.r);
@@ -279,7 +293,7 @@ void carve(WsCarver& c, SideBufs& b, const Plan& p, int64_t M) {
     b.skws_floats = (size_t)3 * 8 * align_up((size_t)M * p.r, 64);     // three towers x 8 K-splits x [M, down]
     {   // ... and the split-K partials of the adapters' weight-gradient products: three towers x <= 32 splits x [D, down]
         size_t wg = 0;
-        for (int z = 0; z < 3; ++z) wg += (size_t)32 * align_up((size_t)p.D[z] * p.r, 64);
+        for (int z = 0; z < 3; ++z) wg += (size_t)2 * 32 * align_up((size_t)p.D[z] * p.r + p.D[z], 64);    // (dWu and dWd of a step share a launch; + the column-sum partials)
         if (wg > b.skws_floats) b.skws_floats = wg;
     }
     b.skws = c.take<float>(b.skws_floats);
@@ -332,7 +346,8 @@ int gemm_group(const Gemm32Prob* pr, int n, int flags, const SideBufs& b, hipStr
         }
         IISAN_TRY(launch_amax_batch(ab, na, s));
     }
-    for (int i = 0; i < nb; ++i) IISAN_TRY(launch_gemm_x3(big[i], flags, b.x3, b.x3_bytes, s));
+    const int gmax = gemm_x3_group_max();
+    for (int i = 0; i < nb; i += gmax) IISAN_TRY(launch_gemm_x3_group(big + i, nb - i < gmax ? nb - i : gmax, flags, b.x3, b.x3_bytes, s));
     // A skinny long-K product (Versa's fc_bert: [1408, 8192] -> 64) must not share a launch with short-K ones: alone it takes the
     // split-K route through the executor's scratch (33 us); grouped, the launch has "enough" workgroups, nothing is split and its
     // 22 workgroups walk 128 K-tiles each while the rest of the chip idles (195 us per Versa step, profiles/r3a_versa_*).
@@ -455,6 +470,7 @@ int setup(Ctx& c, const iisan_side_cfg* cfg, const float* taps_cv, const float* 
 }  // namespace
 
 IISAN_DEV_KNOB(sanb_fused, g_use_sanb);
+IISAN_DEV_KNOB(sidenet_dw_merge, g_dw_merge);
 
 void gemm_x3_set_min_flops(double f);     // negative = the library default (split.hip: X3_DEFAULT_MIN_FLOPS, 4 GFLOP)
 // 0 = off, 1 = library default (the state of a process that never calls this knob), 2 = every product whose shape allows
@@ -507,6 +523,7 @@ extern "C" int iisan_side_net_fwd(const iisan_side_cfg* cfg, const float* taps_c
             pd[i] = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(i)), p.D[zw], c.W(p.dpw(i) + 1), b.DP[i], p.D[2], M, p.D[2], p.D[zw]);
             pd[i].amax_a = b.amax + 9 + i;           // the tap's amax: read again by the weight-gradient product of this step
             pd[i].amax_a_ready = taps_preset ? 1 : 0;
+            pd[i].exact16_a = taps_preset ? 1 : 0;
         }
         IISAN_TRY(gemm_group(pd, p.n[2], 0, b, s));
     }
@@ -675,18 +692,22 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
             pr[a] = prob(b.dO[z], p.D[z], c.W(p.wd(z, k) + 2), r, nullptr, b.dU[z], r, M, r, p.D[z], nullptr, 0, b.U[k][z]);
         }
         IISAN_TRY(launch_gemm32(pr, na, G32_TB | (cfg->gelu ? G32_MUL_GELU_GRAD : G32_MUL_RELU_MASK), s));  // dU
-        for (int a = 0; a < na; ++a) {
-            const int z = sm.z[a], k = sm.k[a];
-            pr[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);
-            pr[a].colsum_a = G(p.wd(z, k) + 3);                                   // dbu += column sums of dO: out of the same product
+        {   // both weight gradients of the step, every tower, in ONE launch (round 6: they were two launches + two reducers; dO is still
+            // whole here — the dF product below overwrites it in place)
+            Gemm32Prob pw[6];
+            for (int a = 0; a < na; ++a) {
+                const int z = sm.z[a], k = sm.k[a];
+                pw[a] = prob(b.dO[z], p.D[z], b.A[k][z], r, nullptr, G(p.wd(z, k) + 2), r, p.D[z], r, M);             // dWu += dO^T · A
+                pw[a].colsum_a = G(p.wd(z, k) + 3);                               // dbu += column sums of dO: out of the same product
+                pw[na + a] = prob(b.dU[z], r, b.F[k][z], p.D[z], nullptr, G(p.wd(z, k)), p.D[z], r, p.D[z], M);       // dWd += dU^T · F
+                pw[na + a].colsum_a = G(p.wd(z, k) + 1);                          // dbd += column sums of dU
+            }
+            if (g_dw_merge) IISAN_TRY(launch_gemm32(pw, 2 * na, G32_TA | G32_TB | G32_ACCUM, s));
+            else {
+                IISAN_TRY(launch_gemm32(pw, na, G32_TA | G32_TB | G32_ACCUM, s));
+                IISAN_TRY(launch_gemm32(pw + na, na, G32_TA | G32_TB | G32_ACCUM, s));
+            }
         }
-        IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWu += dO^T · A
-        for (int a = 0; a < na; ++a) {
-            const int z = sm.z[a], k = sm.k[a];
-            pr[a] = prob(b.dU[z], r, b.F[k][z], p.D[z], nullptr, G(p.wd(z, k)), p.D[z], r, p.D[z], M);
-            pr[a].colsum_a = G(p.wd(z, k) + 1);                                   // dbd += column sums of dU
-        }
-        IISAN_TRY(launch_gemm32(pr, na, G32_TA | G32_TB | G32_ACCUM, s));         // dWd += dU^T · F
         for (int a = 0; a < na; ++a) {
             const int z = sm.z[a], k = sm.k[a];
             pr[a] = prob(b.dU[z], r, c.W(p.wd(z, k)), p.D[z], nullptr, b.dO[z], p.D[z], M, p.D[z], r, b.dO[z], p.D[z]);
@@ -708,7 +729,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
                 kg[a].dgate = G(p.gate(z, k));
                 kg[a].scale_prev = ft.type == 0 ? 1 : 0;
                 kg[a].store = k > 0 ? 1 : 0;          // block 0 starts from zeros / a tap: nobody reads that gradient
-                if (z == 2 && need_dp) { kg[a].d2 = b.dDP; kg[a].ldd2 = p.D[2]; kg[a].d2_is_b = p.text_wide ? 1 : 0; }      // gradient wrt the dim-aligned tap
+                if (z == 2 && need_dp) { kg[a].d2 = b.dDP[sm.mm_i]; kg[a].ldd2 = p.D[2]; kg[a].d2_is_b = p.text_wide ? 1 : 0; }      // gradient wrt the dim-aligned tap
             }
             if (gemm32_k64_gate_ok(pr, kg, na)) {
                 IISAN_TRY(launch_gemm32_k64_gate(pr, kg, na, s));                 // dprev = (1 - g | 1) · (dO + dU · Wd), dθ (in place)
@@ -727,7 +748,7 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
                 fa.t[a].F = b.dO[z];
                 fa.t[a].dgate = cfg->gated ? G(p.gate(z, k)) : nullptr;
                 fa.t[a].da = nullptr; fa.t[a].db = nullptr;
-                if (z == 2 && need_dp) { if (p.text_wide) fa.t[a].db = b.dDP; else fa.t[a].da = b.dDP; }
+                if (z == 2 && need_dp) { if (p.text_wide) fa.t[a].db = b.dDP[sm.mm_i]; else fa.t[a].da = b.dDP[sm.mm_i]; }
                 if (p.D[z] > maxD) maxD = p.D[z];
             }
             // every workgroup ends with ONE atomic on its tower's gate gradient and same-address atomics serialise (~12 ns
@@ -737,21 +758,26 @@ extern "C" int iisan_side_net_bwd(const iisan_side_cfg* cfg, const float* taps_c
             hipLaunchKernelGGL(fuse_bwd_kernel, dim3(gb, na), dim3(256), 0, s, fa);
             IISAN_LAUNCH_OK();
         }
-        if (need_dp) {                        // DP = tap_wide · Pd^T + bd
-            const int zw = p.text_wide ? 1 : 0, i = sm.mm_i;
-            Gemm32Prob pd = prob(b.dDP, p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
-            {
-                const Gemm32Prob f = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(i)), p.D[zw], c.W(p.dpw(i) + 1), b.DP[i], p.D[2], M, p.D[2], p.D[zw]);
-                if (b.x3 && gemm_x3_applicable(f, 0)) { pd.amax_b = b.amax + 9 + i; pd.amax_b_ready = 1; }   // the tap: from the forward dim-align product
-            }
-            IISAN_TRY(gemm_group(&pd, 1, G32_TA | G32_TB | G32_ACCUM | G32_HINT_B_EXACT16, b, s));     // dPd += dDP^T · tap
-            const float* X[1] = {b.dDP};
-            float* O[1] = {G(p.dpw(i) + 1)};
-            int64_t Ms[1] = {M};
-            int32_t Ns[1] = {p.D[2]}, lds[1] = {p.D[2]};
-            IISAN_TRY(launch_colsum(X, O, Ms, Ns, lds, 1, s));
-        }
         // not gated: dprev_z = dF_z, already in dO
+    }
+    if (p.align && p.n[2] > 0) {
+        // DP_i = tap_wide · Pd_i^T + bd_i: the weight gradients of every aligned step as ONE group behind the chain (round 6: they sat
+        // inside their steps — an amax launch and a column-sum launch each; nothing in the chain reads them)
+        Gemm32Prob pd[IISAN_MAX_SIDE];
+        const float* X[IISAN_MAX_SIDE]; float* O[IISAN_MAX_SIDE]; int64_t Ms[IISAN_MAX_SIDE]; int32_t Ns[IISAN_MAX_SIDE], lds[IISAN_MAX_SIDE];
+        const int zw = p.text_wide ? 1 : 0;
+        for (int i = 0; i < p.n[2]; ++i) {
+            const StepMap sm = step_map(p, p.diff_cv + p.diff_t + i);
+            pd[i] = prob(b.dDP[i], p.D[2], c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), nullptr, G(p.dpw(i)), p.D[zw], p.D[2], p.D[zw], M);
+            const Gemm32Prob f = prob(c.tap(zw, sm.k[zw]), (int)c.tap_ld(zw), c.W(p.dpw(i)), p.D[zw], c.W(p.dpw(i) + 1), b.DP[i], p.D[2], M, p.D[2], p.D[zw]);
+            if (b.x3 && gemm_x3_applicable(f, 0)) {       // the tap: from the forward dim-align product
+                pd[i].amax_b = b.amax + 9 + i; pd[i].amax_b_ready = 1;
+                pd[i].exact16_b = cfg->taps_exact16 ? 1 : 0;     // (side_net_fwd preset the slot: scale 1)
+            }
+            X[i] = b.dDP[i]; O[i] = G(p.dpw(i) + 1); Ms[i] = M; Ns[i] = p.D[2]; lds[i] = p.D[2];
+        }
+        IISAN_TRY(gemm_group(pd, p.n[2], G32_TA | G32_TB | G32_ACCUM | G32_HINT_B_EXACT16, b, s));     // dPd_i += dDP_i^T · tap
+        for (int i = 0; i < p.n[2]; i += 4) IISAN_TRY(launch_colsum(X + i, O + i, Ms + i, Ns + i, lds + i, p.n[2] - i < 4 ? p.n[2] - i : 4, s));
     }
     return IISAN_OK;
 }

@@ -25,6 +25,8 @@ struct SplitArgs {
     uint32_t* amax_bits;   // in: bit pattern of max|x| (amax kernel)
     float* inv_scale;      // out: 1/s
     int32_t* lo_flag;      // out: set to 1 when any lo element is non-zero (pre-zeroed; plain stores of the same value)
+    int32_t skip_lo;       // 1: the caller vouches that every element is exact in fp16 at scale 1 (taps cached in fp16, amax slot preset): the lo plane is
+                           // neither computed nor written and the flag stays 0 — the product never reads it (23 MB per [1408, 8192] tap image)
 };
 
 __device__ __forceinline__ void amax_body(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld, uint32_t* amax_bits,
@@ -106,12 +108,12 @@ __device__ __forceinline__ void split1(float xs, _Float16& hi, _Float16& lo) {
 }
 
 // operand row = source row: one thread per 8 consecutive K elements
-__global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
+__device__ __forceinline__ void split_rows_body(const SplitArgs& a, int64_t block, int64_t nblocks) {
     const float s = scale_of(*a.amax_bits);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
+    if (block == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
     const int64_t g8 = a.kp / 8, total = a.out_rows * g8;
     int any_lo = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = block * blockDim.x + threadIdx.x; i < total; i += nblocks * blockDim.x) {
         const int64_t r = i / g8, k = (i - r * g8) * 8;
         h8 hi, lo;
 #pragma unroll
@@ -135,20 +137,20 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) {
         }
         _Float16* o = a.out + r * 2 * a.kp + k;
         *(h8*)o = hi;
+        if (a.skip_lo) continue;
         *(h8*)(o + a.kp) = lo;
         const u4 lb = __builtin_bit_cast(u4, lo);
         any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
     if (__syncthreads_or(any_lo) && threadIdx.x == 0) *a.lo_flag = 1;
 }
+__global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs a) { split_rows_body(a, blockIdx.x, gridDim.x); }
 
-// operand row = source COLUMN (x^T): 64 x 64 tiles transposed through LDS; K runs over the source rows
-__global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
-    __shared__ float T[64][65];
-    const float s = scale_of(*a.amax_bits);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;      // source rows  = K index
-    const int64_t c0 = (int64_t)blockIdx.y * 64;      // source cols  = operand rows
+// operand row = source COLUMN (x^T): 64 x 64 tiles transposed through LDS; K runs over the source rows.  One tile (bx, by) of the
+// (kp / 64) x ceil(out_rows / 64) tile grid; returns whether any lo element of it is non-zero (thread-local)
+__device__ __forceinline__ int split_cols_tile(const SplitArgs& a, float (&T)[64][65], float s, int64_t bx, int64_t by) {
+    const int64_t r0 = bx * 64;      // source rows  = K index
+    const int64_t c0 = by * 64;      // source cols  = operand rows
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -179,11 +181,56 @@ __global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
         }
         _Float16* o = a.out + orow * 2 * a.kp + r0 + kg;
         *(h8*)o = hi;
+        if (a.skip_lo) continue;
         *(h8*)(o + a.kp) = lo;
         const u4 lb = __builtin_bit_cast(u4, lo);
         any_lo |= ((lb[0] | lb[1] | lb[2] | lb[3]) & 0x7fff7fffu) != 0;
     }
-    if (__syncthreads_or(any_lo) && tid == 0) *a.lo_flag = 1;
+    return any_lo;
+}
+__global__ __launch_bounds__(256) void split_cols_kernel(SplitArgs a) {
+    __shared__ float T[64][65];
+    const float s = scale_of(*a.amax_bits);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
+    const int any_lo = split_cols_tile(a, T, s, blockIdx.x, blockIdx.y);
+    if (__syncthreads_or(any_lo) && threadIdx.x == 0) *a.lo_flag = 1;
+}
+
+// the operand images of a GROUP of split-operand products in one launch (blockIdx.y = operand; round 6: Versa's seven dim-align products
+// paid two launches each, forward and weight gradient — 28 launches of 5 - 16 us per step)
+struct SplitBatch { SplitArgs a[16]; };
+__global__ __launch_bounds__(256) void split_batch_kernel(SplitBatch b) {
+    __shared__ float T[64][65];
+    const SplitArgs& a = b.a[blockIdx.y];
+    if (!a.trans) { split_rows_body(a, blockIdx.x, gridDim.x); return; }
+    const float s = scale_of(*a.amax_bits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.inv_scale = 1.0f / s;
+    const int64_t tx = a.kp / 64, ty = (a.out_rows + 63) / 64;
+    int any_lo = 0;
+    for (int64_t t = blockIdx.x; t < tx * ty; t += gridDim.x) {
+        const int64_t by = t / tx, bx = t - by * tx;
+        any_lo |= split_cols_tile(a, T, s, bx, by);
+        __syncthreads();            // T is reused by the next tile
+    }
+    if (__syncthreads_or(any_lo) && threadIdx.x == 0) *a.lo_flag = 1;
+}
+
+// the split-K sums of a group's products in one launch (blockIdx.y = product)
+struct ReduceX3 { const float* P; int32_t ks; int64_t stride; const float* bias; const float* resid; float* C; int64_t M; int32_t N, ldc; };
+struct ReduceX3Batch { ReduceX3 r[8]; };
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(ReduceX3Batch b) {
+    const ReduceX3& r = b.r[blockIdx.y];
+    const int n4 = r.N / 4;
+    const int64_t total = r.M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        f4 v = *(const f4*)(r.P + m * r.N + n);
+        for (int y = 1; y < r.ks; ++y) v += *(const f4*)(r.P + y * r.stride + m * r.N + n);
+        if (r.bias) v += *(const f4*)(r.bias + n);
+        if (r.resid) v += *(const f4*)(r.resid + m * r.ldc + n);
+        *(f4*)(r.C + m * r.ldc + n) = v;
+    }
 }
 
 // C[m][n] = sum_y P[y][m][n] (+ bias[n]) (+ resid[m][n]); 16-byte lanes, fixed summation order
@@ -222,9 +269,10 @@ namespace {
 
 int split_operand(const float* x, bool trans, int64_t op_rows, int64_t K, int64_t ld, _Float16* out,
                   int64_t out_rows, int64_t kp, uint32_t* amax_bits, float* inv_scale, int32_t* lo_flag, hipStream_t s,
-                  bool amax_ready = false) {
+                  bool amax_ready = false, bool skip_lo = false) {
     SplitArgs a{};
     a.lo_flag = lo_flag;
+    a.skip_lo = (skip_lo && amax_ready) ? 1 : 0;
     a.x = x; a.ld = ld; a.out = out; a.out_rows = out_rows; a.kp = kp; a.trans = trans ? 1 : 0;
     a.amax_bits = amax_bits; a.inv_scale = inv_scale;
     a.rows = trans ? K : op_rows;
@@ -334,10 +382,10 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_
     //  kernel reads both flags and skips whichever lo plane is all zeros — an operand that is exact in fp16, like taps cached in fp16)
     flags &= ~G32_HINT_B_EXACT16;
     IISAN_TRY(split_operand(p.A, (flags & G32_TA) != 0, p.M, p.K, p.lda, A16, mp, kp, p.amax_a ? p.amax_a : amax, inv, lo_flag, s,
-                            p.amax_a && p.amax_a_ready));
+                            p.amax_a && p.amax_a_ready, p.exact16_a != 0));
     // B operand rows = N: stored [N,K] by default, [K,N] under G32_TB (then the operand is the source transposed)
     IISAN_TRY(split_operand(p.B, (flags & G32_TB) != 0, p.N, p.K, p.ldb, B16, np, kp, p.amax_b ? p.amax_b : amax + 1, inv + 1, lo_flag + 1, s,
-                            p.amax_b && p.amax_b_ready));
+                            p.amax_b && p.amax_b_ready, p.exact16_b != 0));
     X3pArgs g{};
     g.A2 = A16; g.B2 = B16; g.M = p.M; g.N = p.N; g.kp = (int32_t)kp;
     g.bias = p.bias; g.resid = p.resid; g.out = p.C; g.ldo = p.ldc;
@@ -357,6 +405,96 @@ static int launch_gemm_x3_any(const Gemm32Prob& p, int flags_in, void* ws, size_
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P, ks, g.split_stride, p.bias,
                        accum ? p.C : p.resid, p.C, p.M, p.N, p.ldc);
     IISAN_LAUNCH_OK();
+    return IISAN_OK;
+}
+
+// A GROUP of split-operand products that share flags (the three fc layers of a direction, Versa's dim-align products): ONE launch builds
+// every operand image, the products follow, ONE launch adds the split-K partials of all of them.  Needs every product's zeroed block and
+// both amax slots filled (sidenet.hip: gemm_group batches the amax passes) and the workspace to hold the images of the whole group at once
+// (gemm_x3_group_ws_bytes); otherwise — or with the dev knob x3_group = 0 — the products go one by one through launch_gemm_x3.
+static int g_x3_group = 8;              // products per group (<= 8); 0 / 1: one by one
+IISAN_DEV_KNOB(x3_group, g_x3_group);
+int gemm_x3_group_max() { return g_x3_group < 1 ? 1 : (g_x3_group > 8 ? 8 : g_x3_group); }
+static int64_t g_cnt_x3_group = 0;
+IISAN_DEV_COUNTER(gemm_x3_group, g_cnt_x3_group);
+size_t gemm_x3_group_ws_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int n) {
+    size_t t = 0;
+    for (int i = 0; i < n; ++i) t += align_up(gemm_x3_ws_bytes(M[i], N[i], K[i]), 256);
+    return t;
+}
+int launch_gemm_x3_group(const Gemm32Prob* probs, int n, int flags_in, void* ws, size_t ws_bytes, hipStream_t s) {
+    bool grouped = g_x3_group >= 2 && n >= 2 && n <= 8 && ws;
+    size_t need = 0;
+    for (int i = 0; i < n && grouped; ++i) {
+        const Gemm32Prob& p = probs[i];
+        grouped = p.x3_zeroed && p.amax_a && p.amax_b && p.amax_a_ready && p.amax_b_ready && x3_shape_ok(p, flags_in);
+        need += align_up(gemm_x3_ws_bytes(p.M, p.N, p.K), 256);
+    }
+    if (!grouped || need > ws_bytes) {
+        for (int i = 0; i < n; ++i) IISAN_TRY(launch_gemm_x3_any(probs[i], flags_in, ws, ws_bytes, s));
+        return IISAN_OK;
+    }
+    ++g_cnt_x3_group;
+    g_cnt_x3 += n;
+    const int flags = flags_in & ~G32_HINT_B_EXACT16;
+    const bool accum = (flags & G32_ACCUM) != 0;
+    SplitBatch sb{};
+    ReduceX3Batch rb{};
+    X3pArgs g[8];
+    int ks[8];
+    int nred = 0;
+    int64_t split_blocks = 1, red_blocks = 1;
+    char* w = (char*)ws;
+    for (int i = 0; i < n; ++i) {
+        const Gemm32Prob& p = probs[i];
+        const int64_t kp = ceil_div(p.K, 64) * 64, mp = ceil_div(p.M, 128) * 128, np = ceil_div(p.N, 128) * 128;
+        char* w0 = w;
+        _Float16* A16 = (_Float16*)w;
+        w += align_up((size_t)mp * 2 * kp * 2, 256);
+        _Float16* B16 = (_Float16*)w;
+        w += align_up((size_t)np * 2 * kp * 2, 256);
+        float* P = (float*)(w + 256);
+        w = w0 + align_up(gemm_x3_ws_bytes(p.M, p.N, p.K), 256);
+        char* z48 = (char*)p.x3_zeroed;
+        float* inv = (float*)(z48 + 16);
+        int32_t* lo_flag = (int32_t*)(z48 + 32);
+        for (int o = 0; o < 2; ++o) {
+            SplitArgs& a = sb.a[2 * i + o];
+            const bool trans = (flags & (o ? G32_TB : G32_TA)) != 0;
+            const int64_t op_rows = o ? p.N : p.M;
+            a.x = o ? p.B : p.A; a.ld = o ? p.ldb : p.lda; a.out = o ? B16 : A16; a.out_rows = o ? np : mp; a.kp = kp; a.trans = trans ? 1 : 0;
+            a.amax_bits = o ? p.amax_b : p.amax_a; a.inv_scale = inv + o; a.lo_flag = lo_flag + o;
+            a.skip_lo = (o ? p.exact16_b : p.exact16_a) ? 1 : 0;
+            a.rows = trans ? p.K : op_rows;
+            a.cols = trans ? op_rows : p.K;
+            IISAN_CHECK_SHAPE(a.cols % 4 == 0 && a.ld % 4 == 0 && ((uintptr_t)a.x & 15) == 0, "split: source rows must be 16-byte aligned");
+            const int64_t blocks = trans ? (kp / 64) * ceil_div(a.out_rows, 64) : ceil_div(a.out_rows * (kp / 8), 256);
+            if (blocks > split_blocks) split_blocks = blocks;
+        }
+        g[i] = X3pArgs{};
+        g[i].A2 = A16; g[i].B2 = B16; g[i].M = p.M; g[i].N = p.N; g[i].kp = (int32_t)kp;
+        g[i].bias = p.bias; g[i].resid = p.resid; g[i].out = p.C; g[i].ldo = p.ldc;
+        g[i].inv_a = inv; g[i].inv_b = inv + 1; g[i].lo_a = lo_flag; g[i].lo_b = lo_flag + 1;
+        ks[i] = x3_ksplit(mp, np, kp);
+        if (ks[i] == 1) {
+            if (accum) { IISAN_CHECK_SHAPE(!p.resid, "gemm_x3: accumulate and residual together"); g[i].resid = p.C; }
+        } else {
+            g[i].out = P; g[i].ldo = p.N; g[i].bias = nullptr; g[i].resid = nullptr; g[i].split_stride = p.M * (int64_t)p.N;
+            ReduceX3& r = rb.r[nred++];
+            r.P = P; r.ks = ks[i]; r.stride = g[i].split_stride; r.bias = p.bias; r.resid = accum ? p.C : p.resid; r.C = p.C; r.M = p.M; r.N = p.N; r.ldc = p.ldc;
+            const int64_t blocks = ceil_div(p.M * (p.N / 4), 256);
+            if (blocks > red_blocks) red_blocks = blocks;
+        }
+    }
+    if (split_blocks > 4096) split_blocks = 4096;
+    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)split_blocks, (unsigned)(2 * n)), dim3(256), 0, s, sb);
+    IISAN_LAUNCH_OK();
+    for (int i = 0; i < n; ++i) IISAN_TRY(launch_gemm16_x3p(g[i], ks[i], s));
+    if (nred) {
+        if (red_blocks > 2048) red_blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)red_blocks, (unsigned)nred), dim3(256), 0, s, rb);
+        IISAN_LAUNCH_OK();
+    }
     return IISAN_OK;
 }
 

@@ -159,7 +159,8 @@ typedef struct {
     int32_t first_index_text;
     int32_t taps_exact16;     /* 1: the caller guarantees that every tap value is exactly representable in fp16 (taps cached in fp16, as
                                  preprocess_*.py of Code_Cached_Asym writes them): the split-operand dim-align products then take the tap
-                                 with scale 1 and skip its amax pass.  0 = unknown (always safe)                            */
+                                 with scale 1, skip its amax pass and (round 6) do not build the lo plane of its image — a tap that is NOT
+                                 exact in fp16 would be rounded to fp16 there.  0 = unknown (always safe)                   */
 } iisan_side_cfg;
 
 /* Parameter table (host array of device pointers), n_mm = min(n_cv, n_text):

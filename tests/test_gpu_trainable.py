@@ -1300,14 +1300,16 @@ def test_cached_default_routes_match_the_cpu_oracle_at_bench_size(lib, bs, act):
     assert n_checked == 146
 
 
-@pytest.mark.parametrize("route", ["x3", "sanb", "dw", "gate", "n64f"])
+@pytest.mark.parametrize("route", ["x3", "sanb", "dw", "gate", "n64f", "dwmerge", "x3group"])
 @pytest.mark.parametrize("versa", [False, True])
 def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route):
     """At the batch sizes of BASELINE configs 3 (Cached, bs = 1024) and 5 (Versa shapes, bs = 128): the same step through
     (a) the split-operand fp16 GEMM forced onto every large Linear layer ("x3"), (b) the fused one-launch SANB step
     ("sanb", the product default where the towers' widths allow) and (c) the weight-gradient kernel (`gemm32_dw_kernel`, "dw":
     product default, here against the tiled kernel on the otherwise plain route) and (d) the gated fusion's backward folded into the
-    dF product ("gate", product default on the separate launches, against `fuse_bwd_kernel`) against the plain route — separate fusion kernels and
+    dF product ("gate", product default on the separate launches, against `fuse_bwd_kernel`), (e) round 6: both weight gradients of a SANB step in
+    one launch ("dwmerge", product default, against two launches) and the split-operand products of a launch group sharing one image launch and one
+    split-K sum ("x3group", product default, against one by one; same kernels on the same numbers in the same order) against the plain route — separate fusion kernels and
     f32-matrix-core GEMMs, the path the small fixtures pin to the reference.  Loss within 2e-5, every gradient within 5e-4
     of its scale (2e-3 for the SASRec tensors: 1e-7 differences in the item embeddings flip single ReLU units of its
     feed-forward, seen as 1e-3 on `w_Q.weight` with either route).  GELU adapters: with ReLU a 1e-7 difference in a pre-activation
@@ -1320,7 +1322,9 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
     g = torch.Generator(device="cuda").manual_seed(3)
     out = {}
     for alt in (False, True):
-        _lib.dev_set("x3", 2 if (alt and route == "x3") else 0)
+        _lib.dev_set("x3", 2 if ((alt and route == "x3") or route == "x3group") else 0)
+        _lib.dev_set("x3_group", 1 if (route == "x3group" and not alt) else 8)
+        _lib.dev_set("sidenet_dw_merge", 0 if (route == "dwmerge" and not alt) else 1)
         _lib.dev_set("sanb_fused", 2 if (alt and route == "sanb") else 0)
         _lib.dev_set("gemm32_dw", 0 if (route == "dw" and not alt) else 1)      # "dw": the weight-gradient kernel against the tiled one
         _lib.dev_set("gemm32_k64_gate", 0 if (route == "gate" and not alt) else 1)      # "gate": fusion backward folded into the dF product
@@ -1347,6 +1351,8 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
             out[alt] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad})
         finally:
             _lib.dev_set("x3", 1)
+            _lib.dev_set("x3_group", 8)
+            _lib.dev_set("sidenet_dw_merge", 1)
             _lib.dev_set("sanb_fused", 1)
             _lib.dev_set("gemm32_dw", 1)
             _lib.dev_set("gemm32_k64_gate", 1)
@@ -1361,13 +1367,15 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
         #  between the routes and, through the atomics, between runs — seen at 7e-4)
         assert err < (2e-3 if ("user_encoder" in k or "side_gate" in k) else 5e-4), (k, err)
         differ += int(not torch.equal(g0[k], g1[k]))
-    if not (versa and route == "sanb"):      # Versa's towers have different widths: no fused step there (yet)
+    if route == "x3group":
+        assert l1.item() == l0.item()        # grouping changes the launches, not a single number of the forward pass
+    elif not (versa and route == "sanb"):    # Versa's towers have different widths: no fused step there (yet)
         assert differ > 0                    # the two routes really are different kernels
 
 
 def _route_counts():
     names = ("gemm16_h256", "gemm16_s256", "gemm16_v1", "sanb_fused_fwd", "sanb_fused_bwd", "sasrec_fused_fwd", "gemm_x3", "gemm32_n64f",
-             "gemm32_k64", "gemm32_dw")
+             "gemm32_k64", "gemm32_dw", "gemm_x3_group")
     return {n: _lib.dev_get("count:" + n) for n in names}
 
 
@@ -1384,7 +1392,8 @@ def test_default_dispatch_takes_the_benchmarked_kernel_families_at_the_bench_sha
         embedding + 12 x 4 ViT products + 12 x 4 BERT products), none on the staggered or the 128 x 128 kernels; the seven SANB steps as fused
         launches in both directions; SASRec as one launch; no split-operand product (the fc layers are 1.7 GFLOP each at 1,408 slots);
       * Cached bs = 1024 (config 3): no fused SANB launch (11,264 slots >= 4,096), the fusion-fed down projection / K = 64 / weight-gradient
-        kernels of gemm32.hip instead (7 + 15 + 15 launches), nine split-operand products (three fc layers x forward, dX, dW)."""
+        kernels of gemm32.hip instead (7 + 15 + 8 launches: since round 6 the two weight gradients of a SANB step share a launch), nine
+        split-operand products (three fc layers x forward, dX, dW) as three groups (one image launch and one split-K sum per group)."""
     from iisan_amd import tapstore
     assert _lib.dev_state() == "", "this test is about the library's default routes"
     # ---- the headline ----
@@ -1423,6 +1432,6 @@ def test_default_dispatch_takes_the_benchmarked_kernel_families_at_the_bench_sha
     torch.cuda.synchronize()
     c = _route_counts()
     assert c["sanb_fused_fwd"] == 0 and c["sanb_fused_bwd"] == 0, str(c)
-    assert c["gemm32_n64f"] == 7 and c["gemm32_k64"] == 15 and c["gemm32_dw"] == 15, str(c)
-    assert c["gemm_x3"] == 9 and c["sasrec_fused_fwd"] == 1, str(c)
+    assert c["gemm32_n64f"] == 7 and c["gemm32_k64"] == 15 and c["gemm32_dw"] == 8, str(c)
+    assert c["gemm_x3"] == 9 and c["gemm_x3_group"] == 3 and c["sasrec_fused_fwd"] == 1, str(c)
     _zero_route_counts()
