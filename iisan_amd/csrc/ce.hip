@@ -813,11 +813,521 @@ __global__ __launch_bounds__(256) void ce_colpass_kernel(const float* __restrict
     }
 }
 
-// 1 (default): one fused FWD + DPREC row pass (online softmax) and the cooperative column pass; 2: separate FWD and DPREC
-// row passes (round-2a form); 0: the generic kernel everywhere (test knob)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same two passes on the 16-bit matrix cores with SPLIT operands (the idea of split.hip, inside the loss).
+// At the Cached batch size (bs = 1024: 10,240 x 11,264 logits) the f32-input passes above take 415 + 425 us per step against
+// 2 x 220 us of v_mfma_f32_16x16x4_f32 time: 59 GFLOP on a 157 TF pipe.  Here prec and score are split once per call into
+// fp16 planes, x s = hi + lo (s a power of two from the tensor's amax), and
+//     logits      = (Xh Yh^T + Xh Yl^T + Xl Yh^T) / (sx sy)            3 x v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block
+//     dX^T       += (Yh^T Qh + Yh^T Ql + Yl^T Qh) / (sy 2^10)          Q = the exp / probability registers, split the same way
+// — a 16 x 16 tile pair costs 12 + 12 sixteen-cycle MFMAs instead of 32 thirty-two-cycle ones, the passes become VALU-bound
+// (mask, exp, split: ~25 instructions per logit).  Accuracy as split.hip: 22 mantissa bits of every element within 2^-16 of
+// the tensor's amax, the dropped lo x lo term 2^-22 relative.
+// Shape: a workgroup = 64 x NSUB X rows (a wave owns NSUB blocks of 16) x one of `ysplits` ranges of Y; every step stages 32 Y
+// rows for all four waves — row-major (A operand of the logits) and transposed (A operand of the second product), hi and lo,
+// four contiguous 4 KB blocks of the images ce16_split_kernel wrote — double-buffered, one barrier per step.  A wave keeps
+// its rows' online-softmax state; the per-range partial results meet in a small combine kernel (fixed order: bit-reproducible).
+// The 8 probabilities a lane holds after the two logit tiles of a step ARE the B operand of the second product (K-slot t of
+// lane group g <-> Y row 4g + t | 16 + 4g + (t - 4) of the step: the transposed images are stored in that order).
+constexpr int C16_YLD = 72;            // halves per LDS row of the row-major tile (128 B + 16: conflict-free ds_read_b128)
+constexpr int C16_TLD = 40;            // halves per LDS row of the transposed tile (64 B + 16)
+constexpr float C16_QS = 1024.f;       // the probability registers are split at this scale (they are <= 1 in magnitude)
+constexpr int C16_MAX_YS = 16;
+
+struct Ce16Bufs {
+    uint32_t* amax;            // [2]: bit patterns of max|prec|, max|score|
+    _Float16* img[2][2];       // [prec | score][hi | lo]: row-major [N padded to 32][64]
+    _Float16* imgT[2][2];      // the same rows transposed per group of 32: [group][64][32 slots]
+    float* part_row;           // [ysplits][T][68]: sum_y exp(z - m) score_y (64) | m | l | z_label | -
+    float* part_col;           // [ysplits][M][64]
+};
+
+void carve16(WsCarver& c, Ce16Bufs& b, int64_t bs, int S) {
+    const size_t M = (size_t)bs * (S + 1), T = (size_t)bs * S;
+    const size_t n[2] = {align_up(T, 32), align_up(M, 32)};
+    b.amax = c.take<uint32_t>(4);
+    for (int t = 0; t < 2; ++t)
+        for (int pl = 0; pl < 2; ++pl) {
+            b.img[t][pl] = c.take<_Float16>(n[t] * E);
+            b.imgT[t][pl] = c.take<_Float16>(n[t] * E);
+        }
+    b.part_row = c.take<float>((size_t)C16_MAX_YS * T * 68);
+    b.part_col = c.take<float>((size_t)C16_MAX_YS * M * E);
+}
+
+__device__ __forceinline__ float c16_scale_of(uint32_t amax_bits) {       // as split.hip: the largest element lands in [2^13, 2^14)
+    const int e = (int)(amax_bits >> 23) & 0xff;
+    if (e == 0 || e == 0xff) return 1.0f;
+    return __uint_as_float((uint32_t)(267 - e) << 23);
+}
+
+__global__ __launch_bounds__(256) void ce16_amax_kernel(const float* __restrict__ prec, int64_t n0, const float* __restrict__ score, int64_t n1,
+                                                        uint32_t* amax) {
+    __shared__ float red[4];
+    const float* x = blockIdx.y ? score : prec;
+    const int64_t n4 = (blockIdx.y ? n1 : n0) / 4;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f4 v = ((const f4*)x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(amax + blockIdx.y, __float_as_uint(m));
+    }
+}
+
+// slot of Y row r (0..31) of a step inside the transposed image: lane group g = slot >> 3 holds rows 4g..4g+3 | 16+4g..16+4g+3
+__device__ __forceinline__ int c16_slot(int r) { return r < 16 ? 8 * (r >> 2) + (r & 3) : 8 * ((r - 16) >> 2) + 4 + (r & 3); }
+
+// one workgroup = 32 rows of one tensor (blockIdx.y): the four images of that group
+__global__ __launch_bounds__(256) void ce16_split_kernel(const float* __restrict__ prec, int64_t T, const float* __restrict__ score, int64_t M, Ce16Bufs c) {
+    __shared__ _Float16 sT[2][E][32 + 2];
+    const int t = blockIdx.y;
+    const float* x = t ? score : prec;
+    const int64_t N = t ? M : T, groups = (N + 31) / 32;
+    if ((int64_t)blockIdx.x >= groups) return;
+    const float s = c16_scale_of(c.amax[t]);
+    const int tid = threadIdx.x, r = tid >> 3, c8 = (tid & 7) * 8;
+    const int64_t row = (int64_t)blockIdx.x * 32 + r;
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }
+    if (row < N) {
+        const f4 v0 = *(const f4*)(x + row * E + c8), v1 = *(const f4*)(x + row * E + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = v0[e] * s, bq = v1[e] * s;
+            hi[e] = (_Float16)a; lo[e] = (_Float16)(a - (float)hi[e]);
+            hi[4 + e] = (_Float16)bq; lo[4 + e] = (_Float16)(bq - (float)hi[4 + e]);
+        }
+    }
+    *(h8*)(c.img[t][0] + row * E + c8) = hi;
+    *(h8*)(c.img[t][1] + row * E + c8) = lo;
+    const int slot = c16_slot(r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sT[0][c8 + e][slot] = hi[e]; sT[1][c8 + e][slot] = lo[e]; }
+    __syncthreads();
+    const int er = tid >> 2, p8 = (tid & 3) * 8;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sT[pl][er][p8 + e];
+        *(h8*)(c.imgT[t][pl] + ((int64_t)blockIdx.x * E + er) * 32 + p8) = v;
+    }
+}
+
+// the staged tiles of one step, shared by the four waves
+struct C16Tiles {
+    _Float16 yh[32 * C16_YLD], yl[32 * C16_YLD], th[E * C16_TLD], tl[E * C16_TLD];
+};
+struct C16Stage {      // one thread's share of a step in flight: a 16-byte piece of each of the four tiles
+    h8 yh, yl, th, tl;
+};
+__device__ __forceinline__ void c16_load(C16Stage& st, const Ce16Bufs& c, int ty, int64_t step, int tid) {
+    const int64_t o = step * (32 * E) + tid * 8;
+    st.yh = *(const h8*)(c.img[ty][0] + o);
+    st.yl = *(const h8*)(c.img[ty][1] + o);
+    st.th = *(const h8*)(c.imgT[ty][0] + o);
+    st.tl = *(const h8*)(c.imgT[ty][1] + o);
+}
+__device__ __forceinline__ void c16_store(C16Tiles& t, const C16Stage& st, int tid) {
+    const int yo = (tid >> 3) * C16_YLD + (tid & 7) * 8, to = (tid >> 2) * C16_TLD + (tid & 3) * 8;
+    *(h8*)(t.yh + yo) = st.yh;
+    *(h8*)(t.yl + yo) = st.yl;
+    *(h8*)(t.th + to) = st.th;
+    *(h8*)(t.tl + to) = st.tl;
+}
+// logits^T of one half (16 Y rows) of the step against the 16 X rows whose fragments the lane holds: lane (j, g) -> X row j, Y rows 4g..4g+3
+__device__ __forceinline__ f4 c16_logits(const C16Tiles& t, int half, int j, int g, const h8 (&xh)[2], const h8 (&xl)[2]) {
+    f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int o = (16 * half + j) * C16_YLD + 32 * cc + 8 * g;
+        const h8 ah = *(const h8*)(t.yh + o), al = *(const h8*)(t.yl + o);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[cc], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[cc], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[cc], z, 0, 0, 0);
+    }
+    return z;
+}
+// dacc[et] += Y^T (16 features of block et x the step's 32 rows) · Q (32 rows x the lane's X row), Q split at C16_QS
+__device__ __forceinline__ void c16_second(const C16Tiles& t, int j, int g, const float (&q)[8], f4 (&dacc)[4]) {
+    h8 bh, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = q[e] * C16_QS;
+        bh[e] = (_Float16)v;
+        bl[e] = (_Float16)(v - (float)bh[e]);
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        const int o = (16 * et + j) * C16_TLD + 8 * g;
+        const h8 ah = *(const h8*)(t.th + o), al = *(const h8*)(t.tl + o);
+        dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, dacc[et], 0, 0, 0);
+        dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, dacc[et], 0, 0, 0);
+        dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, dacc[et], 0, 0, 0);
+    }
+}
+
+// Fused forward + d_prec row pass (the online softmax of ce_rowpass_kernel<CE_FUSED>): X = prec, Y = score.  grid (x blocks, ysplits)
+template <int RS1, int NSUB>
+__global__ __launch_bounds__(256) void ce16_rowpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
+    __shared__ __attribute__((aligned(16))) C16Tiles tiles[2];
+    __shared__ __attribute__((aligned(16))) int sMeta[2][96];          // per step: ids[32] | padding[32] | debias[32]
+    const int S1 = S + 1;
+    const int T = bs * S, M = bs * S1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float inv_z = 1.0f / (c16_scale_of(c.amax[0]) * c16_scale_of(c.amax[1]));
+    const float inv_d = 1.0f / (c16_scale_of(c.amax[1]) * C16_QS);
+    h8 xh[NSUB][2], xl[NSUB][2];
+    int row_label[NSUB], row_shift[NSUB], sid[NSUB][RS1];
+    bool xok[NSUB];
+    int xrow[NSUB];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        const int x0 = (blockIdx.x * NSUB + u) * 64 + wave * 16;
+        const int x = x0 + j;
+        xok[u] = x < T;
+        xrow[u] = x;
+        const int xc = xok[u] ? x : T - 1;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            xh[u][cc] = *(const h8*)(c.img[0][0] + (int64_t)xc * E + 32 * cc + 8 * g);
+            xl[u][cc] = *(const h8*)(c.img[0][1] + (int64_t)xc * E + 32 * cc + 8 * g);
+        }
+        const int row_seq = xc / S, seq0 = x0 / S;
+        row_label[u] = row_seq * S1 + (xc - row_seq * S) + 1;
+        row_shift[u] = xok[u] ? (row_seq - seq0) * 16 + 4 * g : 4 * g;
+        const int sq = seq0 + g;
+#pragma unroll
+        for (int p = 0; p < RS1; ++p) sid[u][p] = (p < S1 && sq < bs) ? b.ids32[sq * S1 + p] : -2;
+    }
+    float run_m[NSUB], run_l[NSUB], zlab[NSUB];
+    f4 dacc[NSUB][4];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        run_m[u] = -3.0e38f; run_l[u] = 0.f; zlab[u] = 0.f;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) dacc[u][et] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int steps_total = (M + 31) / 32;
+    const int st0 = blockIdx.y * steps_per;
+    int st1 = st0 + steps_per;
+    if (st1 > steps_total) st1 = steps_total;
+    C16Stage stg;
+    int mreg[3] = {0, 0, 0};
+    auto fetch = [&](int st) {
+        st = st < st1 ? st : st1 - 1;                                   // past the end: the last step again (never used)
+        c16_load(stg, c, 1, st, tid);
+        if (tid < 32) {
+            const int y = st * 32 + tid < M ? st * 32 + tid : M - 1;
+            mreg[0] = b.ids32[y];
+            mreg[1] = b.colpad[y];
+            mreg[2] = __float_as_int(b.debias[y]);
+        }
+    };
+    auto put = [&](int buf) {
+        c16_store(tiles[buf], stg, tid);
+        if (tid < 32) { sMeta[buf][tid] = mreg[0]; sMeta[buf][32 + tid] = mreg[1]; sMeta[buf][64 + tid] = mreg[2]; }
+    };
+    if (st0 < st1) {
+        fetch(st0);
+        put(0);
+        __syncthreads();
+    }
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        fetch(st + 1);
+        const C16Tiles& tl = tiles[buf];
+        const int* meta = sMeta[buf];
+        const int y0 = st * 32;
+        const bool whole = y0 + 32 <= M;                                // block-uniform
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            float fv[8];
+            bool lab[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 z = c16_logits(tl, h, j, g, xh[u], xl[u]);
+                // once per wave and half: (sequence slot g, column j) hit bits and the 16 column-padding bits
+                const int idc = meta[16 * h + j];
+                bool hit = false;
+#pragma unroll
+                for (int p = 0; p < RS1; ++p) hit |= sid[u][p] == idc;
+                const unsigned long long hm = __ballot(hit);
+                const unsigned pm = (unsigned)__ballot(meta[32 + 16 * h + j] != 0);
+                const unsigned hit4 = (unsigned)(hm >> row_shift[u]) & 0xfu;
+                const unsigned pad4 = (pm >> (4 * g)) & 0xfu;
+                const f4 deb4 = *(const f4*)(meta + 64 + 16 * h + 4 * g);
+                const int lab_r = row_label[u] - (y0 + 16 * h + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool is_lab = lab_r == r;
+                    const bool masked = ((pad4 >> r) & 1u) | (((hit4 >> r) & 1u) & (is_lab ? 0u : 1u));
+                    const float val = masked ? MASKV : z[r] * inv_z - deb4[r];
+                    const bool yok = whole || (y0 + 16 * h + 4 * g + r < M);
+                    fv[4 * h + r] = yok ? val : -INFINITY;
+                    lab[4 * h + r] = yok && is_lab;
+                }
+            }
+            float m8 = fv[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) m8 = fmaxf(m8, fv[e]);
+            if (__ballot(m8 > run_m[u])) {                               // wave-uniform and rare after the first steps
+                float mr = fmaxf(m8, __shfl_xor(m8, 16, 64));
+                mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+                const float mn = fmaxf(run_m[u], mr);
+                const float f = fexp(run_m[u] - mn);                     // run_m starts at -3e38: f = 0 on the first step
+                run_l[u] *= f;
+#pragma unroll
+                for (int et = 0; et < 4; ++et) dacc[u][et] *= f;
+                run_m[u] = mn;
+            }
+            float q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q[e] = fexp(fv[e] - run_m[u]);                           // structural padding: exp(-inf) = 0
+                run_l[u] += q[e];
+                if (lab[e]) zlab[u] = fv[e];
+            }
+            c16_second(tl, j, g, q, dacc[u]);
+        }
+        put(buf ^ 1);
+        __syncthreads();
+    }
+    // per-range partial results of the wave's rows (the four lanes of a row share run_m; their sums add up)
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            run_l[u] += __shfl_xor(run_l[u], o, 64);
+            zlab[u] += __shfl_xor(zlab[u], o, 64);
+        }
+        if (!xok[u]) continue;
+        float* out = c.part_row + ((int64_t)blockIdx.y * T + xrow[u]) * 68;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *(f4*)(out + 16 * et + 4 * g) = dacc[u][et] * inv_d;
+        if (g == 0) *(f4*)(out + E) = (f4){run_m[u], run_l[u], zlab[u], 0.f};
+    }
+}
+
+// lse, row loss and d_prec (for d_loss = 1) from the per-range partial results: the ranges brought to the common maximum, fixed order
+__global__ __launch_bounds__(256) void ce16_row_combine_kernel(const float* __restrict__ score, const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c,
+                                                               int bs, int S, int ysplits) {
+    const int S1 = S + 1, T = bs * S;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int xr = i >> 6, e = i & 63;
+    if (xr >= T) return;
+    float m = -3.0e38f;
+    for (int y = 0; y < ysplits; ++y) m = fmaxf(m, c.part_row[((int64_t)y * T + xr) * 68 + E]);
+    float l = 0.f, acc = 0.f, zl = 0.f;
+    for (int y = 0; y < ysplits; ++y) {
+        const float* p = c.part_row + ((int64_t)y * T + xr) * 68;
+        const float f = fexp(p[E] - m);
+        l += p[E + 1] * f;
+        acc += p[e] * f;
+        zl += p[E + 2];
+    }
+    const bool valid = log_mask[xr] != 0.f;
+    const int sq = xr / S, lab = sq * S1 + (xr - sq * S) + 1;
+    b.dprec[(int64_t)xr * E + e] = valid ? (acc / l - score[(int64_t)lab * E + e]) / b.nvalid[0] : 0.f;
+    if (e == 0) {
+        const float lse = m + logf(l);
+        b.lse[xr] = lse;
+        b.rowloss[xr] = valid ? lse - zl : 0.f;
+    }
+}
+
+// The column-fixed pass (d_score = dZ^T · prec): X = score (a lane owns one column), Y = prec.  grid (x blocks, ysplits)
+template <int RS1, int NSUB>
+__global__ __launch_bounds__(256) void ce16_colpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
+    __shared__ __attribute__((aligned(16))) C16Tiles tiles[2];
+    __shared__ __attribute__((aligned(16))) int sIds[2][128];          // per half: ids of its four sequence slots, 16 per slot
+    __shared__ __attribute__((aligned(16))) int sRow[2][4][32];        // per Y row: slot within its half | label column | lse | valid
+    const int S1 = S + 1;
+    const int T = bs * S, M = bs * S1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float inv_z = 1.0f / (c16_scale_of(c.amax[0]) * c16_scale_of(c.amax[1]));
+    const float inv_d = 1.0f / (c16_scale_of(c.amax[0]) * C16_QS);
+    h8 xh[NSUB][2], xl[NSUB][2];
+    int col_id[NSUB], xcol[NSUB];
+    bool col_pad[NSUB], xok[NSUB];
+    float col_debias[NSUB];
+    f4 dacc[NSUB][4];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        const int x = (blockIdx.x * NSUB + u) * 64 + wave * 16 + j;
+        xok[u] = x < M;
+        xcol[u] = x;
+        const int xc = xok[u] ? x : M - 1;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            xh[u][cc] = *(const h8*)(c.img[1][0] + (int64_t)xc * E + 32 * cc + 8 * g);
+            xl[u][cc] = *(const h8*)(c.img[1][1] + (int64_t)xc * E + 32 * cc + 8 * g);
+        }
+        col_id[u] = b.ids32[xc];
+        col_pad[u] = b.colpad[xc] != 0;
+        col_debias[u] = b.debias[xc];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) dacc[u][et] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int steps_total = (T + 31) / 32;
+    const int st0 = blockIdx.y * steps_per;
+    int st1 = st0 + steps_per;
+    if (st1 > steps_total) st1 = steps_total;
+    C16Stage stg;
+    int mreg[4] = {0, 0, 0, 0};
+    auto fetch = [&](int st) {
+        st = st < st1 ? st : st1 - 1;
+        c16_load(stg, c, 0, st, tid);
+        if (tid < 128) {                       // thread (half, slot, id index): id of the half's sequence slot
+            const int h = tid >> 6, sl = (tid >> 4) & 3, k = tid & 15;
+            const int sq = (st * 32 + 16 * h) / S + sl;
+            mreg[0] = (k < S1 && sq < bs) ? b.ids32[sq * S1 + k] : -2;
+        } else if (tid < 160) {                // one Y row each
+            const int r = tid - 128, y = st * 32 + r;
+            const int yc = y < T ? y : T - 1;
+            const int rs = yc / S;
+            const int sl = rs - (st * 32 + 16 * (r >> 4)) / S;          // 0..3 for real rows (S >= 5); rows past T never count
+            mreg[0] = sl < 0 ? 0 : (sl > 3 ? 3 : sl);
+            mreg[1] = rs * S1 + (yc - rs * S) + 1;
+            mreg[2] = __float_as_int(b.lse[yc]);
+            mreg[3] = __float_as_int((y < T && log_mask[yc] != 0.f) ? 1.f : 0.f);
+        }
+    };
+    auto put = [&](int buf) {
+        c16_store(tiles[buf], stg, tid);
+        if (tid < 128) sIds[buf][tid] = mreg[0];
+        else if (tid < 160) {
+            const int r = tid - 128;
+            sRow[buf][0][r] = mreg[0]; sRow[buf][1][r] = mreg[1]; sRow[buf][2][r] = mreg[2]; sRow[buf][3][r] = mreg[3];
+        }
+    };
+    if (st0 < st1) {
+        fetch(st0);
+        put(0);
+        __syncthreads();
+    }
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        fetch(st + 1);
+        const C16Tiles& tl = tiles[buf];
+        const int y0 = st * 32;
+        const bool whole = y0 + 32 <= T;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            float q[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 z = c16_logits(tl, h, j, g, xh[u], xl[u]);
+                bool hit = false;
+#pragma unroll
+                for (int qq = 0; qq < (RS1 + 3) / 4; ++qq) {
+                    const i4 v = *(const i4*)(sIds[buf] + 64 * h + 16 * g + 4 * qq);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * qq + k < RS1) hit |= v[k] == col_id[u];
+                }
+                const unsigned long long hm = __ballot(hit);            // bit 16 * slot + j
+                const i4 slot4 = *(const i4*)(sRow[buf][0] + 16 * h + 4 * g);
+                const i4 lab4 = *(const i4*)(sRow[buf][1] + 16 * h + 4 * g);
+                const f4 lse4 = *(const f4*)(sRow[buf][2] + 16 * h + 4 * g);
+                const f4 ok4 = *(const f4*)(sRow[buf][3] + 16 * h + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool is_lab = lab4[r] == xcol[u];
+                    const bool hb = (hm >> (16 * slot4[r] + j)) & 1ull;
+                    const bool masked = col_pad[u] | (hb & !is_lab);
+                    const float val = masked ? MASKV : z[r] * inv_z - col_debias[u];
+                    const bool yok = whole || (y0 + 16 * h + 4 * g + r < T);
+                    const float pr = fexp(val - lse4[r]);
+                    q[4 * h + r] = (yok && xok[u]) ? (pr - (is_lab ? 1.f : 0.f)) * ok4[r] : 0.f;
+                }
+            }
+            c16_second(tl, j, g, q, dacc[u]);
+        }
+        put(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        if (!xok[u]) continue;
+        float* out = c.part_col + ((int64_t)blockIdx.y * M + xcol[u]) * E;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *(f4*)(out + 16 * et + 4 * g) = dacc[u][et] * inv_d;
+    }
+}
+
+__global__ __launch_bounds__(256) void ce16_col_combine_kernel(CeBufs b, Ce16Bufs c, int64_t n4, int ysplits, float d_loss, float* __restrict__ d_score) {
+    const float sc = d_loss / b.nvalid[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f4 v = ((const f4*)c.part_col)[i];
+        for (int y = 1; y < ysplits; ++y) v += ((const f4*)c.part_col)[(int64_t)y * n4 + i];
+        ((f4*)d_score)[i] = v * sc;
+    }
+}
+
+// 1 (default): one fused FWD + DPREC row pass (online softmax) and the cooperative column pass — on the 16-bit matrix cores with split
+// operands (ce16_*) from C16_MIN_LOGITS logits on, on the f32 cores below; 2: separate FWD and DPREC row passes (round-2a form); 0: the
+// generic kernel everywhere; 3: ce16_* at every size; 4: the f32 fused passes at every size (test knobs)
 int g_ce_fast = 1;
 constexpr int g_ce_dbg = 0;      // (the ablation bits of the fused row pass: compile-time zero since round 5)
+// bs = 128 (1,280 x 1,408 logits): 29 us per f32 pass, launch-sized — the split route's four extra small launches would cost more than it gains
+constexpr int64_t C16_MIN_LOGITS = (int64_t)1 << 24;
 bool rowpass_ok(int64_t bs, int S) { return g_ce_fast && S >= 5 && S + 1 <= MAXS1 && bs * (int64_t)(S + 1) < (1ll << 31); }
+bool fused_ok(int64_t bs, int S) { return rowpass_ok(bs, S) && (g_ce_fast == 1 || g_ce_fast == 3 || g_ce_fast == 4); }
+bool ce16_ok(int64_t bs, int S) {
+    return rowpass_ok(bs, S) && (g_ce_fast == 3 || (g_ce_fast == 1 && bs * S * bs * (int64_t)(S + 1) >= C16_MIN_LOGITS));
+}
+// ranges of Y per X block: the workgroup count that fills whole rounds of the chip best (one workgroup per CU and round; >= 4 x CUs wanted,
+// >= 8 steps per range), the fewest ranges among equals
+int ce16_ysplits(int64_t nx, int64_t ny, int nsub) {
+    const int64_t xb = ceil_div(nx, (int64_t)64 * nsub), steps = ceil_div(ny, (int64_t)32), cus = iisan_cu_count();
+    int best = 1;
+    double best_eff = -1.0;
+    for (int ys = 1; ys <= C16_MAX_YS; ++ys) {
+        if (ys > 1 && steps / ys < 8) break;
+        const int64_t w = xb * ys;
+        double eff = (double)w / (double)(ceil_div(w, cus) * cus);
+        if (w < 4 * cus) eff *= 0.5 + 0.5 * (double)w / (double)(4 * cus);      // too few workgroups to hide a wave's latencies behind another's
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ys; }
+    }
+    return best;
+}
+template <int NSUB>
+int launch_ce16_row(const float* log_mask, const CeBufs& b, const Ce16Bufs& c, int64_t bs, int S, hipStream_t s, int* ys_out) {
+    const int64_t T = bs * S, M = bs * (S + 1);
+    const int ys = ce16_ysplits(T, M, NSUB);
+    const int steps_per = (int)ceil_div(ceil_div(M, (int64_t)32), (int64_t)ys);
+    const dim3 grid((unsigned)ceil_div(T, (int64_t)64 * NSUB), (unsigned)ys);
+    if (S + 1 <= 11) hipLaunchKernelGGL((ce16_rowpass_kernel<11, NSUB>), grid, dim3(256), 0, s, log_mask, b, c, (int)bs, S, steps_per);
+    else hipLaunchKernelGGL((ce16_rowpass_kernel<MAXS1, NSUB>), grid, dim3(256), 0, s, log_mask, b, c, (int)bs, S, steps_per);
+    IISAN_LAUNCH_OK();
+    *ys_out = ys;
+    return IISAN_OK;
+}
+template <int NSUB>
+int launch_ce16_col(const float* log_mask, const CeBufs& b, const Ce16Bufs& c, int64_t bs, int S, hipStream_t s, int* ys_out) {
+    const int64_t T = bs * S, M = bs * (S + 1);
+    const int ys = ce16_ysplits(M, T, NSUB);
+    const int steps_per = (int)ceil_div(ceil_div(T, (int64_t)32), (int64_t)ys);
+    const dim3 grid((unsigned)ceil_div(M, (int64_t)64 * NSUB), (unsigned)ys);
+    if (S + 1 <= 11) hipLaunchKernelGGL((ce16_colpass_kernel<11, NSUB>), grid, dim3(256), 0, s, log_mask, b, c, (int)bs, S, steps_per);
+    else hipLaunchKernelGGL((ce16_colpass_kernel<MAXS1, NSUB>), grid, dim3(256), 0, s, log_mask, b, c, (int)bs, S, steps_per);
+    IISAN_LAUNCH_OK();
+    *ys_out = ys;
+    return IISAN_OK;
+}
+int g_ce16_nsub = 1;             // X blocks of 16 rows per wave (1 or 2)
 
 int check(int64_t bs, int S, int Ein) {
     IISAN_CHECK_SHAPE(bs > 0 && S >= 1 && S <= 63, "inbatch_ce: bs %lld / S %d unsupported", (long long)bs, S);
@@ -830,15 +1340,20 @@ int check(int64_t bs, int S, int Ein) {
 extern "C" size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S) {
     WsCarver c(nullptr, 0);
     CeBufs b;
+    Ce16Bufs b16;
     carve(c, b, bs, S);
+    carve16(c, b16, bs, S);
     return c.off;
 }
 
-// the forward call's token: a tag, the call shape and the route it took
-static uint64_t ce_token(int64_t bs, int32_t S, int fused) {
-    return 0xCE00000000000000ull | ((uint64_t)(bs & 0xFFFFFFFFll) << 16) | ((uint64_t)(S & 0xFF) << 8) | (uint64_t)(fused ? 2 : 1);
+// the forward call's token: a tag, the call shape and the route it took (1 = separate / generic passes, 2 = fused f32 row pass, 3 = split-operand passes)
+static uint64_t ce_token(int64_t bs, int32_t S, int route) {
+    return 0xCE00000000000000ull | ((uint64_t)(bs & 0xFFFFFFFFll) << 16) | ((uint64_t)(S & 0xFF) << 8) | (uint64_t)(route + 1);
 }
 IISAN_DEV_KNOB(ce_fast, g_ce_fast);
+IISAN_DEV_KNOB(ce16_nsub, g_ce16_nsub);
+static int64_t g_cnt_ce16 = 0;            // forward calls on the split-operand route (route counter, common.h)
+IISAN_DEV_COUNTER(ce16, g_cnt_ce16);
 
 extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
                                     const float* pop_prob, int64_t n_pop, int64_t bs, int32_t S, int32_t Ein, float* loss,
@@ -848,7 +1363,9 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_CHECK_SHAPE(n_pop > 0, "inbatch_ce_fwd: empty pop_prob table");
     WsCarver c(ws, ws_bytes);
     CeBufs b;
+    Ce16Bufs b16;
     carve(c, b, bs, S);
+    carve16(c, b16, bs, S);
     if (c.overflow || !ws) {
         iisan_set_error("inbatch_ce_fwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
@@ -858,14 +1375,33 @@ extern "C" int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, cons
     IISAN_LAUNCH_OK();
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, log_mask, T, b.nvalid);
     IISAN_LAUNCH_OK();
+    if (ce16_ok(bs, S)) {
+        // split-operand route: amax -> images -> fused row pass per Y range -> combine (lse, row loss, d_prec for d_loss = 1 in the workspace)
+        IISAN_CHECK_SHAPE(fwd_token != nullptr, "inbatch_ce_fwd: fwd_token must not be null");
+        *fwd_token = ce_token(bs, S, 2);
+        ++g_cnt_ce16;
+        IISAN_HIP_OK(hipMemsetAsync(b16.amax, 0, 16, s));
+        hipLaunchKernelGGL(ce16_amax_kernel, dim3(64, 2), dim3(256), 0, s, prec, T * E, score, M * E, b16.amax);
+        IISAN_LAUNCH_OK();
+        hipLaunchKernelGGL(ce16_split_kernel, dim3((unsigned)ceil_div(M, 32), 2), dim3(256), 0, s, prec, T, score, M, b16);
+        IISAN_LAUNCH_OK();
+        int ys = 1;
+        if (g_ce16_nsub == 2) IISAN_TRY(launch_ce16_row<2>(log_mask, b, b16, bs, S, s, &ys));
+        else IISAN_TRY(launch_ce16_row<1>(log_mask, b, b16, bs, S, s, &ys));
+        hipLaunchKernelGGL(ce16_row_combine_kernel, dim3((unsigned)ceil_div(T * E, 256)), dim3(256), 0, s, score, log_mask, b, b16, (int)bs, S, ys);
+        IISAN_LAUNCH_OK();
+        hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, b.rowloss, T, b.nvalid, loss);
+        IISAN_LAUNCH_OK();
+        return IISAN_OK;
+    }
     // fast path: the forward pass leaves d_prec (for d_loss = 1) in the workspace, the backward call only scales it — the
     // route goes back to the caller as a token, so that the backward call follows what THIS call did, not the knob's later
     // value, and the library keeps no per-call state
     IISAN_CHECK_SHAPE(fwd_token != nullptr, "inbatch_ce_fwd: fwd_token must not be null");
-    *fwd_token = ce_token(bs, S, (rowpass_ok(bs, S) && g_ce_fast == 1) ? 1 : 0);
-    if (rowpass_ok(bs, S) && g_ce_fast == 1 && S + 1 <= 11)
+    *fwd_token = ce_token(bs, S, fused_ok(bs, S) ? 1 : 0);
+    if (fused_ok(bs, S) && S + 1 <= 11)
         hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr, g_ce_dbg);
-    else if (rowpass_ok(bs, S) && g_ce_fast == 1)
+    else if (fused_ok(bs, S))
         hipLaunchKernelGGL((ce_rowpass_kernel<CE_FUSED, MAXS1>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score, log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
     else if (rowpass_ok(bs, S) && S + 1 <= 11) hipLaunchKernelGGL((ce_rowpass_kernel<CE_FWD, 11>), dim3((unsigned)ceil_div(T, 16)), dim3(256), 0, s, prec, score,
                        log_mask, b, (int)bs, S, 0.f, (float*)nullptr);
@@ -888,13 +1424,26 @@ extern "C" int iisan_inbatch_ce_bwd(const int64_t* ids, const float* score, cons
     IISAN_TRY(check(bs, S, Ein));
     WsCarver c(ws, ws_bytes);
     CeBufs b;
+    Ce16Bufs b16;
     carve(c, b, bs, S);       // ids32/debias/colpad/lse/nvalid were filled by the forward call on the same workspace
+    carve16(c, b16, bs, S);   // ... and, on the split-operand route, the operand images and their amax
     if (c.overflow || !ws) {
         iisan_set_error("inbatch_ce_bwd: workspace too small (%zu < %zu)", ws_bytes, c.off);
         return IISAN_EWORKSPACE;
     }
     const int64_t T = bs * S, M = bs * (S + 1);
-    const bool fused = fwd_token == ce_token(bs, S, 1);
+    const bool split16 = fwd_token == ce_token(bs, S, 2);
+    const bool fused = split16 || fwd_token == ce_token(bs, S, 1);
+    if (split16) {            // whatever the dev switch says by now: the images this route needs are in the workspace
+        hipLaunchKernelGGL(ce_scale_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(T * E / 4, 256), 1024)), dim3(256), 0, s, b.dprec, d_loss, d_prec, T * E / 4);
+        IISAN_LAUNCH_OK();
+        int ys = 1;
+        if (g_ce16_nsub == 2) IISAN_TRY(launch_ce16_col<2>(log_mask, b, b16, bs, S, s, &ys));
+        else IISAN_TRY(launch_ce16_col<1>(log_mask, b, b16, bs, S, s, &ys));
+        hipLaunchKernelGGL(ce16_col_combine_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(M * E / 4, 256), 2048)), dim3(256), 0, s, b, b16, M * E / 4, ys, d_loss, d_score);
+        IISAN_LAUNCH_OK();
+        return IISAN_OK;
+    }
     if (!fused && fwd_token != ce_token(bs, S, 0)) {
         iisan_set_error("inbatch_ce_bwd: fwd_token %llx is not what inbatch_ce_fwd returns for bs = %lld, S = %d", (unsigned long long)fwd_token, (long long)bs, S);
         return IISAN_EBADSHAPE;

@@ -886,13 +886,43 @@ def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(l
         assert (g16[k] - g32[k]).abs().max().item() <= tol * (g32[k].abs().max().item() + 1e-20), k
 
 
-@pytest.mark.parametrize("ce_fast", [1, 2, 0])
+@pytest.mark.parametrize("bs,S,lengths_seed,dup", [(7, 5, 1, False), (37, 10, 2, True), (130, 7, 3, True), (64, 10, 4, False), (3, 15, 5, True)])
+@pytest.mark.parametrize("nsub", [1, 2])
+def test_split_operand_ce_matches_the_oracle_on_ragged_shapes(lib, bs, S, lengths_seed, dup, nsub):
+    """Round 6: the loss on the 16-bit matrix cores with split operands (`ce16_*`, csrc/ce.hip), forced at sizes the CPU oracle finishes in
+    seconds (`ce_fast = 3`; the product takes it from 2^24 logits on).  Shapes that leave partial 16-row blocks, partial 32-row steps,
+    empty Y ranges and sequences of every length; duplicated items (the false-negative mask) and history padding (the column mask).
+    Loss within 2e-5 of `oracle.inbatch_ce` (`Code_Uncached/model/model.py:81-104`), gradients within 2e-4 of their scale."""
+    import random
+    rnd = random.Random(lengths_seed)
+    lengths = [rnd.randint(2, S + 1) for _ in range(bs)]
+    n = max(40, bs * 3)
+    b = synth.scientific_batch(bs=bs, seed=90 + lengths_seed, item_num=n, res=2, words=2, lengths=lengths, dup_items=dup, seq_len=S)
+    g = torch.Generator().manual_seed(lengths_seed)
+    E = 64
+    score = (torch.randn(bs * (S + 1), E, generator=g) * 0.4)
+    prec = (torch.randn(bs * S, E, generator=g) * 0.4)
+    sc, pc = score.cuda().requires_grad_(True), prec.cuda().requires_grad_(True)
+    before = _lib.dev_get("count:ce16")
+    with _lib.dev(ce_fast=3, ce16_nsub=nsub):
+        loss = ops.InbatchCeFn.apply(b.ids.view(-1).cuda(), sc, pc, b.log_mask.cuda(), b.pop_prob.cuda())
+        loss.backward()
+    assert _lib.dev_get("count:ce16") == before + 1
+    so, po = score.clone().requires_grad_(True), prec.clone().requires_grad_(True)
+    ref = O.inbatch_ce(b.ids, so, po, b.log_mask, b.pop_prob)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    _close(sc.grad.cpu(), so.grad, 2e-4, 1e-9, "d_score (split operands)")
+    _close(pc.grad.cpu(), po.grad, 2e-4, 1e-9, "d_prec (split operands)")
+
+
+@pytest.mark.parametrize("ce_fast", [1, 2, 0, 4])
 def test_inbatch_ce_at_cached_batch_size_matches_the_formula(lib, ce_fast):
     """BASELINE config C3 (Cached, bs = 1024): logits [10240, 11264].  The fused loss and both gradients against the
     reference's formula (`model.py:81-104`, as restated in oracle.inbatch_logits) evaluated in fp64 on the device —
     the oracle itself is CPU-sized; its formula is checked against the reference goldens at small sizes."""
     from iisan_amd import synth
-    _lib.dev_set("ce_fast", ce_fast)        # 1 = product default (fused online-softmax row pass), 2 = separate FWD / DPREC row passes, 0 = generic kernel
+    _lib.dev_set("ce_fast", ce_fast)        # 1 = product default (at this size: split operands on the 16-bit matrix cores), 4 = fused f32 row pass, 2 = separate FWD / DPREC row passes, 0 = generic kernel
     bs, S, E = 1024, 10, 64
     b = synth.scientific_batch(bs=bs, seed=77, res=2, words=2, dup_items=True)     # ids / log_mask / pop_prob (tiny content)
     g = torch.Generator().manual_seed(5)
