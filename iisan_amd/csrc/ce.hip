@@ -965,21 +965,31 @@ __device__ __forceinline__ void c16_second(const C16Tiles& t, int j, int g, cons
         bh[e] = (_Float16)v;
         bl[e] = (_Float16)(v - (float)bh[e]);
     }
+    // fragments one feature block ahead, fenced: left alone the compiler requests all eight up front (32 registers that cost the pass a wave of occupancy)
+    const int o0 = j * C16_TLD + 8 * g;
+    h8 ah = *(const h8*)(t.th + o0), al = *(const h8*)(t.tl + o0);
 #pragma unroll
     for (int et = 0; et < 4; ++et) {
-        const int o = (16 * et + j) * C16_TLD + 8 * g;
-        const h8 ah = *(const h8*)(t.th + o), al = *(const h8*)(t.tl + o);
+        h8 nh = ah, nl = al;
+        if (et < 3) {
+            nh = *(const h8*)(t.th + o0 + 16 * (et + 1) * C16_TLD);
+            nl = *(const h8*)(t.tl + o0 + 16 * (et + 1) * C16_TLD);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, dacc[et], 0, 0, 0);
         dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, dacc[et], 0, 0, 0);
         dacc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, dacc[et], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh; al = nl;
     }
 }
 
 // Fused forward + d_prec row pass (the online softmax of ce_rowpass_kernel<CE_FUSED>): X = prec, Y = score.  grid (x blocks, ysplits)
 template <int RS1, int NSUB>
-__global__ __launch_bounds__(256) void ce16_rowpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
+__global__ __launch_bounds__(256, NSUB == 1 ? 4 : 2) void ce16_rowpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
     __shared__ __attribute__((aligned(16))) C16Tiles tiles[2];
     __shared__ __attribute__((aligned(16))) int sMeta[2][96];          // per step: ids[32] | padding[32] | debias[32]
+    __shared__ __attribute__((aligned(16))) int sSid[4][NSUB][64];     // per wave and X block: the ids of its four sequence slots, 16 per slot
     const int S1 = S + 1;
     const int T = bs * S, M = bs * S1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(256) void ce16_rowpass_kernel(const float* __restri
     const float inv_z = 1.0f / (c16_scale_of(c.amax[0]) * c16_scale_of(c.amax[1]));
     const float inv_d = 1.0f / (c16_scale_of(c.amax[1]) * C16_QS);
     h8 xh[NSUB][2], xl[NSUB][2];
-    int row_label[NSUB], row_shift[NSUB], sid[NSUB][RS1];
+    int row_label[NSUB], row_shift[NSUB];
     bool xok[NSUB];
     int xrow[NSUB];
 #pragma unroll
@@ -1006,8 +1016,7 @@ __global__ __launch_bounds__(256) void ce16_rowpass_kernel(const float* __restri
         row_label[u] = row_seq * S1 + (xc - row_seq * S) + 1;
         row_shift[u] = xok[u] ? (row_seq - seq0) * 16 + 4 * g : 4 * g;
         const int sq = seq0 + g;
-#pragma unroll
-        for (int p = 0; p < RS1; ++p) sid[u][p] = (p < S1 && sq < bs) ? b.ids32[sq * S1 + p] : -2;
+        sSid[wave][u][lane] = (j < S1 && sq < bs) ? b.ids32[sq * S1 + j] : -2;      // (read back by the same wave only; the first barrier below orders it)
     }
     float run_m[NSUB], run_l[NSUB], zlab[NSUB];
     f4 dacc[NSUB][4];
@@ -1059,8 +1068,16 @@ __global__ __launch_bounds__(256) void ce16_rowpass_kernel(const float* __restri
                 // once per wave and half: (sequence slot g, column j) hit bits and the 16 column-padding bits
                 const int idc = meta[16 * h + j];
                 bool hit = false;
+                {
+                    typedef int i4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int p = 0; p < RS1; ++p) hit |= sid[u][p] == idc;
+                    for (int qq = 0; qq < (RS1 + 3) / 4; ++qq) {
+                        const i4 v = *(const i4*)(sSid[wave][u] + 16 * g + 4 * qq);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (4 * qq + k < RS1) hit |= v[k] == idc;
+                    }
+                }
                 const unsigned long long hm = __ballot(hit);
                 const unsigned pm = (unsigned)__ballot(meta[32 + 16 * h + j] != 0);
                 const unsigned hit4 = (unsigned)(hm >> row_shift[u]) & 0xfu;
@@ -1147,7 +1164,7 @@ __global__ __launch_bounds__(256) void ce16_row_combine_kernel(const float* __re
 
 // The column-fixed pass (d_score = dZ^T · prec): X = score (a lane owns one column), Y = prec.  grid (x blocks, ysplits)
 template <int RS1, int NSUB>
-__global__ __launch_bounds__(256) void ce16_colpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
+__global__ __launch_bounds__(256, NSUB == 1 ? 4 : 2) void ce16_colpass_kernel(const float* __restrict__ log_mask, CeBufs b, Ce16Bufs c, int bs, int S, int steps_per) {
     __shared__ __attribute__((aligned(16))) C16Tiles tiles[2];
     __shared__ __attribute__((aligned(16))) int sIds[2][128];          // per half: ids of its four sequence slots, 16 per slot
     __shared__ __attribute__((aligned(16))) int sRow[2][4][32];        // per Y row: slot within its half | label column | lse | valid
@@ -1288,20 +1305,17 @@ bool fused_ok(int64_t bs, int S) { return rowpass_ok(bs, S) && (g_ce_fast == 1 |
 bool ce16_ok(int64_t bs, int S) {
     return rowpass_ok(bs, S) && (g_ce_fast == 3 || (g_ce_fast == 1 && bs * S * bs * (int64_t)(S + 1) >= C16_MIN_LOGITS));
 }
-// ranges of Y per X block: the workgroup count that fills whole rounds of the chip best (one workgroup per CU and round; >= 4 x CUs wanted,
-// >= 8 steps per range), the fewest ranges among equals
+// ranges of Y per X block: about seven workgroups per CU (four are resident at a time) and >= 8 steps per range.  Same-box sweep at bs = 1024
+// (tools/ce_sweep.py, forward + backward of the loss, both passes with the same count): 4 ranges 402 - 407 us, 6 390, 8 365, 10 355 - 357,
+// 11 347 - 348, 12 357, 16 353; the f32 passes 852 - 891.
+int g_ce16_ys = 0;               // > 0: this many Y ranges (sweeps)
 int ce16_ysplits(int64_t nx, int64_t ny, int nsub) {
+    if (g_ce16_ys > 0) return g_ce16_ys > C16_MAX_YS ? C16_MAX_YS : g_ce16_ys;
     const int64_t xb = ceil_div(nx, (int64_t)64 * nsub), steps = ceil_div(ny, (int64_t)32), cus = iisan_cu_count();
-    int best = 1;
-    double best_eff = -1.0;
-    for (int ys = 1; ys <= C16_MAX_YS; ++ys) {
-        if (ys > 1 && steps / ys < 8) break;
-        const int64_t w = xb * ys;
-        double eff = (double)w / (double)(ceil_div(w, cus) * cus);
-        if (w < 4 * cus) eff *= 0.5 + 0.5 * (double)w / (double)(4 * cus);      // too few workgroups to hide a wave's latencies behind another's
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = ys; }
-    }
-    return best;
+    int64_t ys = (7 * cus + xb / 2) / xb;
+    if (ys > C16_MAX_YS) ys = C16_MAX_YS;
+    while (ys > 1 && steps / ys < 8) --ys;
+    return ys < 1 ? 1 : (int)ys;
 }
 template <int NSUB>
 int launch_ce16_row(const float* log_mask, const CeBufs& b, const Ce16Bufs& c, int64_t bs, int S, hipStream_t s, int* ys_out) {
@@ -1352,6 +1366,7 @@ static uint64_t ce_token(int64_t bs, int32_t S, int route) {
 }
 IISAN_DEV_KNOB(ce_fast, g_ce_fast);
 IISAN_DEV_KNOB(ce16_nsub, g_ce16_nsub);
+IISAN_DEV_KNOB(ce16_ys, g_ce16_ys);
 static int64_t g_cnt_ce16 = 0;            // forward calls on the split-operand route (route counter, common.h)
 IISAN_DEV_COUNTER(ce16, g_cnt_ce16);
 

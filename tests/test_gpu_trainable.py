@@ -1405,7 +1405,7 @@ def test_alternative_routes_at_bench_size_equal_the_plain_path(lib, versa, route
 
 def _route_counts():
     names = ("gemm16_h256", "gemm16_s256", "gemm16_v1", "sanb_fused_fwd", "sanb_fused_bwd", "sasrec_fused_fwd", "gemm_x3", "gemm32_n64f",
-             "gemm32_k64", "gemm32_dw", "gemm_x3_group")
+             "gemm32_k64", "gemm32_dw", "gemm_x3_group", "ce16")
     return {n: _lib.dev_get("count:" + n) for n in names}
 
 
@@ -1444,7 +1444,7 @@ def test_default_dispatch_takes_the_benchmarked_kernel_families_at_the_bench_sha
         c = _route_counts()
     assert c["gemm16_h256"] == 97 and c["gemm16_s256"] == 0 and c["gemm16_v1"] == 0, str(c)
     assert c["sanb_fused_fwd"] == 7 and c["sanb_fused_bwd"] == 7 and c["gemm32_n64f"] == 0, str(c)
-    assert c["sasrec_fused_fwd"] == 1 and c["gemm_x3"] == 0, str(c)
+    assert c["sasrec_fused_fwd"] == 1 and c["gemm_x3"] == 0 and c["ce16"] == 0, str(c)      # (1.8 M logits: the f32 loss passes)
     del model, tr
     torch.cuda.empty_cache()
     # ---- config 3 ----
@@ -1464,4 +1464,5 @@ def test_default_dispatch_takes_the_benchmarked_kernel_families_at_the_bench_sha
     assert c["sanb_fused_fwd"] == 0 and c["sanb_fused_bwd"] == 0, str(c)
     assert c["gemm32_n64f"] == 7 and c["gemm32_k64"] == 15 and c["gemm32_dw"] == 8, str(c)
     assert c["gemm_x3"] == 9 and c["gemm_x3_group"] == 3 and c["sasrec_fused_fwd"] == 1, str(c)
+    assert c["ce16"] == 1, str(c)            # 115 M logits: the loss on the 16-bit matrix cores with split operands
     _zero_route_counts()
