@@ -219,6 +219,9 @@ int iisan_sasrec_bwd(const iisan_sasrec_cfg* cfg, const float* x, const float* l
  * log_mask fp32 [bs,S], pop_prob fp32 [n_pop = item_num+1].  loss: 1 float.  row_lse: [bs*S] scratch kept for bwd.
  * The library never syncs, so a bad INPUT VALUE cannot come back as a return code: an id outside [0, n_pop) is
  * not dereferenced and makes the loss NaN (the reference would raise an IndexError at model.py:63).
+ * From 2^24 logits on (bs = 1024: 10,240 x 11,264) the two passes run on the 16-bit matrix cores with score / prec split
+ * into fp16 hi + lo planes (csrc/ce.hip ce16_*: the accuracy of an fp32 product to ~2^-22; the workspace also holds the
+ * operand images and the per-range partial results: ~95 MB at bs = 1024); below, on the f32-input matrix cores.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t iisan_inbatch_ce_ws_bytes(int64_t bs, int32_t S);
 int iisan_inbatch_ce_fwd(const int64_t* ids, const float* score, const float* prec, const float* log_mask,
