@@ -887,11 +887,12 @@ def test_versa_fp16_tap_stores_take_the_exact_tap_route_without_changing_a_bit(l
 
 
 @pytest.mark.parametrize("bs,S,lengths_seed,dup", [(7, 5, 1, False), (37, 10, 2, True), (130, 7, 3, True), (64, 10, 4, False), (3, 15, 5, True)])
-@pytest.mark.parametrize("nsub", [1, 2])
-def test_split_operand_ce_matches_the_oracle_on_ragged_shapes(lib, bs, S, lengths_seed, dup, nsub):
+@pytest.mark.parametrize("nsub,ys", [(1, 0), (2, 0), (1, 16)])
+def test_split_operand_ce_matches_the_oracle_on_ragged_shapes(lib, bs, S, lengths_seed, dup, nsub, ys):
     """Round 6: the loss on the 16-bit matrix cores with split operands (`ce16_*`, csrc/ce.hip), forced at sizes the CPU oracle finishes in
     seconds (`ce_fast = 3`; the product takes it from 2^24 logits on).  Shapes that leave partial 16-row blocks, partial 32-row steps,
-    empty Y ranges and sequences of every length; duplicated items (the false-negative mask) and history padding (the column mask).
+    EMPTY Y ranges (ys = 16 forces sixteen ranges on two to fifty steps) and sequences of every length; duplicated items (the false-negative mask)
+    and history padding (the column mask); one and two 16-row blocks per wave.
     Loss within 2e-5 of `oracle.inbatch_ce` (`Code_Uncached/model/model.py:81-104`), gradients within 2e-4 of their scale."""
     import random
     rnd = random.Random(lengths_seed)
@@ -904,7 +905,7 @@ def test_split_operand_ce_matches_the_oracle_on_ragged_shapes(lib, bs, S, length
     prec = (torch.randn(bs * S, E, generator=g) * 0.4)
     sc, pc = score.cuda().requires_grad_(True), prec.cuda().requires_grad_(True)
     before = _lib.dev_get("count:ce16")
-    with _lib.dev(ce_fast=3, ce16_nsub=nsub):
+    with _lib.dev(ce_fast=3, ce16_nsub=nsub, ce16_ys=ys):
         loss = ops.InbatchCeFn.apply(b.ids.view(-1).cuda(), sc, pc, b.log_mask.cuda(), b.pop_prob.cuda())
         loss.backward()
     assert _lib.dev_get("count:ce16") == before + 1
