@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void gemm16_x3p_kernel(X3pArgs p) {
 }  // namespace
 
 // tile width of a product: 192 columns where that turns a partly filled last round into none (x3p_tile_n, shared with the K-split choice of split.hip)
+static int g_x3_bn = 0;                  // 128 / 192: this tile width wherever it divides N (sweeps); 0 = by the rule below
+IISAN_DEV_KNOB(x3_force_bn, g_x3_bn);
 int x3p_tile_n(int64_t M, int64_t N) {
+    if (g_x3_bn == 128 || (g_x3_bn == 192 && N % 192 == 0)) return g_x3_bn;
     const int64_t slots = (int64_t)2 * iisan_cu_count(), rows = ceil_div(M, XBM);
     const int64_t t128 = rows * ceil_div(N, 128), t192 = rows * ceil_div(N, 192);
     if (N % 192 != 0) return 128;                      // (whole tiles only: the W image is padded to 128-row multiples)

@@ -307,7 +307,10 @@ int launch_gemm16_f32(const Gemm16Args& a, int ksplit, hipStream_t s);      // g
 // splits = 440 workgroups, ONE round of 52), and every split costs a pass over its partial (written and read back: ~8 bytes per output).
 //   cost(ks) = ceil(tiles ks / slots) x (steps / ks + 4) K-step times (~1 us)  +  [ks > 1] ks x (8 M N bytes at ~5 TB/s)
 int x3p_tile_n(int64_t M, int64_t N);          // gemm16_x3.hip: 128 or 192 columns per tile
+static int g_x3_ks = 0;                  // > 0: this many K splits for every product (sweeps); 0 = by the cost estimate
+IISAN_DEV_KNOB(x3_force_ks, g_x3_ks);
 static int x3_ksplit(int64_t mp, int64_t np, int64_t kp) {
+    if (g_x3_ks > 0) return g_x3_ks > 16 ? 16 : g_x3_ks;
     const int bn = x3p_tile_n(mp, np);
     const int64_t tiles = (mp / 128) * ceil_div(np, bn), steps = kp / 32 * bn / 128, slots = (int64_t)2 * iisan_cu_count();
     int best = 1;
