@@ -59,7 +59,14 @@ __global__ void ce_prep_kernel(const int64_t* __restrict__ ids, const float* __r
 __global__ __launch_bounds__(256) void ce_count_kernel(const float* __restrict__ log_mask, int64_t T, float* out) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < T; i += 256) s += log_mask[i] != 0.f ? 1.f : 0.f;
+    // (16-byte loads, all of a thread's requests in flight: one dependent 4-byte load per iteration made this single-workgroup pass 10.7 us at T = 10,240;
+    //  the counts are small integers: any summation order is exact)
+    const int64_t T4 = (T % 4 == 0 && ((uintptr_t)log_mask & 15) == 0) ? T / 4 : 0;
+    for (int64_t i = threadIdx.x; i < T4; i += 256) {
+        const f4 v = ((const f4*)log_mask)[i];
+        s += (v[0] != 0.f ? 1.f : 0.f) + (v[1] != 0.f ? 1.f : 0.f) + (v[2] != 0.f ? 1.f : 0.f) + (v[3] != 0.f ? 1.f : 0.f);
+    }
+    for (int64_t i = 4 * T4 + threadIdx.x; i < T; i += 256) s += log_mask[i] != 0.f ? 1.f : 0.f;
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -73,7 +80,13 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
                                                         float* loss) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < T; i += 256) s += rowloss[i];
+    // 16-byte loads (as ce_count_kernel); the order is fixed — thread t adds the groups t, t + 256, ... of four rows, each as (r0 + r1) + (r2 + r3)
+    const int64_t T4 = (T % 4 == 0 && ((uintptr_t)rowloss & 15) == 0) ? T / 4 : 0;
+    for (int64_t i = threadIdx.x; i < T4; i += 256) {
+        const f4 v = ((const f4*)rowloss)[i];
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int64_t i = 4 * T4 + threadIdx.x; i < T; i += 256) s += rowloss[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
